@@ -1,0 +1,201 @@
+/*
+ * ls1hip.h — C ABI of libls1hip, the MI355X-native linked-cell pair-force engine.
+ *
+ * This is the drop-in boundary for ONE hot path of ls1-MarDyn (reference: reinago/ls1-mardyn):
+ *   LinkedCells traversal -> VectorizedCellProcessor pair kernel -> Leapfrog integrator (+ ghost-cell halo).
+ * Every entry point names the reference interface it replaces (paths relative to /root/reference/src).
+ * Host adapters (C++17 classes with the reference's ParticleContainer / CellProcessor / Integrator signatures,
+ * or the Python mirror in ls1-mardyn_amd/) call ONLY these functions.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, FP64 only (the reference's MARDYN_DPDP build).
+ *   - every function returns 0 on success, <0 on error (LS1HIP_E*); ls1hip_last_error() gives the text.
+ *     (reference convention: log + Simulation::exit(code), Simulation.cpp:155-158 — adapters translate.)
+ *   - the caller owns every host buffer; the library owns device memory and HIP streams; no pointer passed in
+ *     is retained after the call returns.  `dev_*` arguments are DEVICE pointers (e.g. torch tensor data_ptr()).
+ *   - entry points are main-thread only and internally asynchronous on the context's HIP streams
+ *     (reference threading contract: SURVEY.md 8b).
+ *   - molecule arrays are AoS [n][k] row-major exactly like the reference's Molecule fields:
+ *     r[3], v[3], q[4]=(w,x,y,z), D[3] (angular momentum), F[3], M[3], Vi[3]; cid is 0-based.
+ */
+#ifndef LS1HIP_H_
+#define LS1HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ls1hip_ctx ls1hip_ctx;
+
+enum {
+	LS1HIP_OK = 0,
+	LS1HIP_EINVAL = -1,   /* bad argument / call order                                   */
+	LS1HIP_EHIP = -2,     /* HIP runtime error                                           */
+	LS1HIP_ENOMEM = -3,   /* device allocation failed / capacity exceeded                */
+	LS1HIP_ELOST = -4,    /* a molecule left the halo region (reference: "particle lost")*/
+	LS1HIP_ENODEV = -5    /* no usable gfx950 device                                     */
+};
+
+/* site table strides (doubles per site), same column order as the reference's .inp component block
+ * (io/ASCIIReader.cpp:178-206) with the LJ shift already reduced to shift6 (molecules/Component.cpp:105-118) */
+#define LS1HIP_LJ_STRIDE 7 /* x y z m eps sigma shift6 */
+#define LS1HIP_CH_STRIDE 5 /* x y z m q                */
+#define LS1HIP_DP_STRIDE 7 /* x y z ex ey ez absMy     */
+#define LS1HIP_QP_STRIDE 7 /* x y z ex ey ez absQ      */
+
+/* force-kernel variants (ls1hip_set_option "force_kernel") */
+#define LS1HIP_FK_AUTO 0      /* fastest parity-green kernel for the component set           */
+#define LS1HIP_FK_GENERIC 1   /* thread-per-molecule, global-memory neighbours (any density) */
+#define LS1HIP_FK_LDS_LIST 2  /* brick-tiled, LDS-staged, per-lane neighbour lists (1CLJ)    */
+
+/* ---- lifetime ------------------------------------------------------------------------------------------------- */
+
+/* Create a context on HIP device `device` (one process per GPU; multi-GPU = one context per rank).
+ * Replaces: construction of LinkedCells + VectorizedCellProcessor + Leapfrog in Simulation::readXML /
+ * prepare_start (Simulation.cpp:411-455, 768-779, 168-186). */
+int ls1hip_create(int device, ls1hip_ctx** out);
+int ls1hip_destroy(ls1hip_ctx* ctx);
+/* Text of the last error on this context (never NULL).  ctx may be NULL for creation errors. */
+const char* ls1hip_last_error(const ls1hip_ctx* ctx);
+/* Library version / build target string, e.g. "ls1hip 0.1 gfx950". */
+const char* ls1hip_version(void);
+
+/* Integer options: "force_kernel" (LS1HIP_FK_*), "cells_in_cutoff" (1|2, LinkedCells <cellsInCutoffRadius>,
+ * particleContainer/LinkedCells.h:81-106), "compute_vi" (0|1 per-molecule virial Vi output),
+ * "deterministic" (0|1 canonical in-cell order by molecule id). */
+int ls1hip_set_option(ls1hip_ctx* ctx, const char* name, long value);
+int ls1hip_get_option(const ls1hip_ctx* ctx, const char* name, long* value);
+
+/* ---- model ---------------------------------------------------------------------------------------------------- */
+
+/* Component set + cutoffs -> device parameter tables.
+ * Replaces: Comp2Param::initialize (molecules/Comp2Param.cpp:10-187), the table build in
+ * VectorizedCellProcessor::VectorizedCellProcessor (adapter/VectorizedCellProcessor.cpp:21-83) and
+ * Ensemble::setComponentLookUpIDs (ensemble/EnsembleBase.cpp:88-101).
+ * nlj/nc/nd/nq: [ncomp] site counts; lj/ch/dp/qp: flat site tables (component-major, strides above);
+ * mass: [ncomp]; I: [ncomp][3] principal moments; mix: [ncomp*(ncomp-1)/2][2] = (xi, eta) for i<j in reader
+ * order (io/ASCIIReader.cpp:221-230); eps_rf: reaction-field epsilon; rc / rc_lj: cutoffs. */
+int ls1hip_set_components(ls1hip_ctx* ctx, int ncomp, const int* nlj, const int* nc, const int* nd, const int* nq,
+						  const double* lj, const double* ch, const double* dp, const double* qp, const double* mass,
+						  const double* I, const double* mix, double eps_rf, double rc, double rc_lj);
+
+/* Read back the derived LJ table ([ncenters][ncenters] each; ncenters = sum nlj) — for parity tests of the
+ * parameter derivation.  Any pointer may be NULL. */
+int ls1hip_get_lj_table(const ls1hip_ctx* ctx, int* ncenters, double* eps24, double* sig2, double* shift6);
+
+/* Domain of THIS rank: bounding box [box_min, box_max) inside the global periodic box of edge global_len
+ * (origin 0).  neighbor_rank[27]: rank owning the region in direction (sx,sy,sz) in {-1,0,1}^3, index
+ * (sz+1)*9+(sy+1)*3+(sx+1); an entry equal to `my_rank` means "periodic image handled locally", -1 means
+ * open boundary (no halo from that side).  For a single GPU pass all entries = my_rank (periodic) or -1 (open).
+ * Replaces: LinkedCells::LinkedCells / rebuild (particleContainer/LinkedCells.cpp:42-109,136-204),
+ * DomainDecompBase::getBoundingBoxMin/Max and DomainDecomposition grid setup
+ * (parallel/DomainDecomposition.cpp:19-41,112-123). */
+int ls1hip_set_domain(ls1hip_ctx* ctx, const double global_len[3], const double box_min[3], const double box_max[3],
+					  int my_rank, const int neighbor_rank[27]);
+/* Cell grid chosen for the domain: dims[3] incl. halo layers, cell_len[3]. */
+int ls1hip_get_grid(const ls1hip_ctx* ctx, int dims[3], double cell_len[3], int* halo_width);
+
+/* ---- molecules ------------------------------------------------------------------------------------------------ */
+
+/* Replace the molecule set of this rank (all must lie inside [box_min, box_max)).
+ * Replaces: ParticleContainer::addParticles (particleContainer/ParticleContainer.h:108-130).
+ * q and D may be NULL (unit quaternion / zero angular momentum). */
+int ls1hip_upload(ls1hip_ctx* ctx, size_t n, const uint64_t* id, const int32_t* cid, const double* r, const double* v,
+				  const double* q, const double* D);
+/* Number of molecules owned by this rank / halo copies currently held. */
+int ls1hip_count(const ls1hip_ctx* ctx, size_t* n_owned, size_t* n_halo);
+
+/* Download owned molecules in device (cell-sorted) order.  Any pointer may be NULL.
+ * Replaces: ParticleContainer::iterator(ONLY_INNER_AND_BOUNDARY) read access (ParticleContainer.h:150-170). */
+int ls1hip_download_state(ls1hip_ctx* ctx, size_t cap, uint64_t* id, int32_t* cid, double* r, double* v, double* q,
+						  double* D);
+/* Forces of the last ls1hip_forces call, same order as ls1hip_download_state.
+ * Replaces: Molecule::F / M / Vi after Simulation::updateForces -> calcFM (Simulation.cpp:752-762). */
+int ls1hip_download_forces(ls1hip_ctx* ctx, size_t cap, double* F, double* M, double* Vi);
+
+/* ---- the time step, piecewise (mirrors Simulation::simulate, Simulation.cpp:995-1099) ----------------------- */
+
+/* Leapfrog::eventNewTimestep -> FullMolecule::upd_preF (integrators/Leapfrog.cpp:48-64,
+ * molecules/FullMolecule.cpp:334-364): v += dt/2m F; r += dt v; quaternion / L half steps. */
+int ls1hip_kick_drift(ls1hip_ctx* ctx, double dt);
+
+/* LinkedCells::update (LinkedCells.cpp:243-356): re-sort owned molecules into cells; molecules that left the box
+ * through a side whose neighbor_rank is this rank are wrapped (DomainDecompBase::handleDomainLeavingParticles,
+ * parallel/DomainDecompBase.cpp:174-225); molecules leaving towards other ranks are packed for export
+ * (see ls1hip_export_*). */
+int ls1hip_rebin(ls1hip_ctx* ctx);
+
+/* Halo population for all directions handled locally (DomainDecompBase::populateHaloLayerWithCopies,
+ * parallel/DomainDecompBase.cpp:293-348) and packing of halo copies for remote directions; then
+ * LinkedCells::updateMoleculeCaches (LinkedCells.cpp:1054-1086: site expansion, F/M/Vi cleared). */
+int ls1hip_halo(ls1hip_ctx* ctx);
+
+/* LinkedCells::traverseCells(VectorizedCellProcessor) + Simulation::updateForces (LinkedCells.cpp:564-575,
+ * VectorizedCellProcessor.cpp:111-157,796-2821; FullMolecule::calcFM molecules/FullMolecule.cpp:526-629).
+ * upot / virial = the values the reference passes to Domain::setLocalUpot / setLocalVirial
+ * (VectorizedCellProcessor.cpp:155-156) for THIS rank; each pair that crosses a rank/periodic boundary is
+ * counted half on each side, so the sum over ranks equals the reference's global value.
+ * which: 0 = all cells, 1 = inner cells only (no halo cell in the neighbourhood;
+ * LinkedCells::traversePartialInnermostCells), 2 = the remaining (boundary) cells
+ * (LinkedCells::traverseNonInnermostCells) — the reference's comm/compute overlap split
+ * (parallel/NonBlockingMPIMultiStepHandler.cpp:30-97).  Results of 1 then 2 accumulate. */
+int ls1hip_forces(ls1hip_ctx* ctx, int which, double* upot, double* virial);
+
+/* Leapfrog::eventForcesCalculated -> FullMolecule::upd_postF (Leapfrog.cpp:66-150, FullMolecule.cpp:366-389):
+ * v += dt_half/m F; L += dt_half M; returns sum m v^2, sum I w^2, N, rotational DOF (thermostat 0). */
+int ls1hip_kick(ls1hip_ctx* ctx, double dt_half, double* summv2, double* sumIw2, uint64_t* n, uint64_t* rot_dof);
+
+/* nsteps full time steps entirely on the device (single rank, all directions local), no host round trip
+ * inside: the loop body of Simulation::simulate (Simulation.cpp:979-1167) for an NVE run without plugins.
+ * out6 (may be NULL) = {upot, virial, summv2, sumIw2, N, rotDOF} of the LAST step. */
+int ls1hip_run(ls1hip_ctx* ctx, double dt, unsigned long nsteps, double* out6);
+
+/* ---- multi-GPU plumbing: packed buffers a host transport (RCCL via torch.distributed, MPI, ...) moves ---------
+ * Wire formats (little endian, FP64): leaving molecule = 15 doubles {id(as bits), cid(as bits), r3, v3, q4, D3}
+ * (the reference's 116-byte record, parallel/CommunicationBuffer.cpp:131-145, padded to 120); halo molecule =
+ * 9 doubles {id, cid, r3, q4} (reference 68-byte record, CommunicationBuffer.cpp:167-176, padded to 72).
+ * Positions are already shifted into the receiver's frame.
+ * Replaces: CommunicationPartner::initSend / unpack (parallel/CommunicationPartner.cpp:139-227,266-389). */
+#define LS1HIP_LEAVING_DOUBLES 15
+#define LS1HIP_HALO_DOUBLES 9
+/* kind: 0 = leaving molecules (valid after ls1hip_rebin), 1 = halo copies (valid after ls1hip_halo).
+ * counts[27]: molecules packed per direction (0 for local / open directions). */
+int ls1hip_export_counts(ls1hip_ctx* ctx, int kind, uint64_t counts[27]);
+/* Copy the packed records of direction `dir` into the DEVICE buffer dev_buf (capacity in records). */
+int ls1hip_export_pack(ls1hip_ctx* ctx, int kind, int dir, void* dev_buf, size_t cap);
+/* Append `n` received records from DEVICE buffer dev_buf: kind 0 -> owned molecules (then call ls1hip_rebin
+ * again is NOT needed: they are binned on arrival), kind 1 -> halo copies.  Call ls1hip_import_done(kind)
+ * after the last import of a kind. */
+int ls1hip_import(ls1hip_ctx* ctx, int kind, const void* dev_buf, size_t n);
+int ls1hip_import_done(ls1hip_ctx* ctx, int kind);
+
+/* ---- seam A: CellProcessor-level drop-in (no container replacement) -------------------------------------------
+ * One call = one complete traversal over the cells the reference's LinkedCells holds, given as a flat cell-major
+ * molecule list.  Replaces the body of VectorizedCellProcessor::processCell / processCellPair / endTraversal
+ * (adapter/VectorizedCellProcessor.cpp:124-157,2734-2821) when the adapter batches at endTraversal
+ * (seam A).  cell_dims[3]: the reference's _cellsPerDimension incl. halo; cell_start[ncells+1]:
+ * first molecule of each cell in the flat arrays; r/q/cid: molecule data incl. halo molecules;
+ * outputs F/M/Vi [n][3] (halo entries are written as 0) and upot/virial with the reference's macroscopic rule. */
+int ls1hip_soa_forces(ls1hip_ctx* ctx, const int cell_dims[3], const uint32_t* cell_start, size_t n, const double* r,
+					  const double* q, const int32_t* cid, double* F, double* M, double* Vi, double* upot,
+					  double* virial);
+
+/* ---- measurement ---------------------------------------------------------------------------------------------- */
+
+/* Device time (ms, HIP events on the context's compute stream) and launch count accumulated per kernel class
+ * since the last reset: names[] in {"force","integrate","rebin","halo"}. */
+int ls1hip_timing(ls1hip_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);
+int ls1hip_timing_reset(ls1hip_ctx* ctx);
+/* Enable (1) / disable (0) per-launch HIP-event timing (adds a little host overhead). */
+int ls1hip_timing_enable(ls1hip_ctx* ctx, int on);
+/* Pair statistics of the last force call: distance checks and in-range molecule pairs (as FlopCounter counts
+ * them, adapter/FlopCounter.cpp:20-76); requires option "count_pairs"=1. */
+int ls1hip_pair_stats(ls1hip_ctx* ctx, uint64_t* dist_checks, uint64_t* pairs_in_range);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LS1HIP_H_ */

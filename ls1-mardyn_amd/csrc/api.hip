@@ -1,0 +1,1047 @@
+// api.hip — the C ABI of libls1hip (include/ls1hip.h): context, parameter-table derivation, device memory,
+// and the orchestration of the kernels of one time step.  Host C++17; every entry point cites the reference
+// interface it replaces in the header.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "common.hpp"
+
+using namespace ls1;
+
+static thread_local std::string g_create_err = "";
+
+#define FAIL(ctx, code, ...)                                   \
+	do {                                                       \
+		char _b[512];                                          \
+		snprintf(_b, sizeof(_b), __VA_ARGS__);                 \
+		(ctx)->err = _b;                                       \
+		return (code);                                         \
+	} while (0)
+
+#define HIPCHK(ctx, call)                                                                              \
+	do {                                                                                               \
+		hipError_t _e = (call);                                                                        \
+		if (_e != hipSuccess) FAIL(ctx, LS1HIP_EHIP, "%s failed: %s", #call, hipGetErrorString(_e)); \
+	} while (0)
+
+#define REQUIRE(ctx, cond, ...) \
+	do {                        \
+		if (!(cond)) FAIL(ctx, LS1HIP_EINVAL, __VA_ARGS__); \
+	} while (0)
+
+// ---- timing --------------------------------------------------------------------------------------------------------
+struct TimedScope {
+	ls1hip_ctx* c;
+	Timer* t;
+	hipEvent_t stop = nullptr;
+	TimedScope(ls1hip_ctx* ctx, Timer& tm) : c(ctx), t(&tm) {
+		if (!c->timing_on) return;
+		if (t->used + 2 > t->ev.size()) {
+			hipEvent_t a, b;
+			if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+			t->ev.push_back(a);
+			t->ev.push_back(b);
+		}
+		hipEventRecord(t->ev[t->used], c->stream);
+		stop = t->ev[t->used + 1];
+		t->used += 2;
+		t->launches++;
+	}
+	~TimedScope() {
+		if (stop) hipEventRecord(stop, c->stream);
+	}
+};
+
+static void timer_collect(Timer& t) {
+	for (size_t i = 0; i + 1 < t.used; i += 2) {
+		float ms = 0.f;
+		hipEventSynchronize(t.ev[i + 1]);
+		if (hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]) == hipSuccess) t.total_ms += ms;
+	}
+	t.used = 0;
+}
+static void timer_free(Timer& t) {
+	for (auto e : t.ev) hipEventDestroy(e);
+	t.ev.clear();
+	t.used = 0;
+}
+
+// ---- memory helpers ------------------------------------------------------------------------------------------------
+template <class T>
+static int dalloc(ls1hip_ctx* c, T** p, size_t n) {
+	*p = nullptr;
+	void* q = nullptr;
+	hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
+	if (e != hipSuccess) FAIL(c, LS1HIP_ENOMEM, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
+	*p = (T*)q;
+	return 0;
+}
+template <class T>
+static void dfree(T*& p) {
+	if (p) hipFree((void*)p);
+	p = nullptr;
+}
+
+static void free_mol(ls1hip_ctx* c) {
+	for (int k = 0; k < 2; ++k) {
+		MolSoA& m = c->mol[k];
+		dfree(m.x); dfree(m.y); dfree(m.z); dfree(m.vx); dfree(m.vy); dfree(m.vz);
+		dfree(m.q0); dfree(m.q1); dfree(m.q2); dfree(m.q3); dfree(m.Dx); dfree(m.Dy); dfree(m.Dz);
+		dfree(m.id); dfree(m.cid);
+	}
+	ForceSoA& f = c->frc;
+	dfree(f.Fx); dfree(f.Fy); dfree(f.Fz); dfree(f.Mx); dfree(f.My); dfree(f.Mz); dfree(f.Vix); dfree(f.Viy); dfree(f.Viz);
+	HaloStage& h = c->hs;
+	dfree(h.x); dfree(h.y); dfree(h.z); dfree(h.q0); dfree(h.q1); dfree(h.q2); dfree(h.q3); dfree(h.id); dfree(h.cid);
+	dfree(h.key); dfree(h.rank);
+	dfree(c->d_key); dfree(c->d_rank); dfree(c->d_perm); dfree(c->d_ckey);
+	dfree(c->d_partials);
+	dfree(c->d_exp_leave); dfree(c->d_exp_halo);
+	c->cap_real = c->cap_halo = 0;
+	c->partials_cap = 0;
+}
+static void free_cells(ls1hip_ctx* c) {
+	dfree(c->d_count); dfree(c->d_cell_begin); dfree(c->d_cell_end); dfree(c->d_blocksum);
+	c->cells_alloc = 0;
+}
+
+// ---- lifetime ------------------------------------------------------------------------------------------------------
+extern "C" const char* ls1hip_version(void) { return "ls1hip 0.1 gfx950"; }
+
+extern "C" const char* ls1hip_last_error(const ls1hip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int ls1hip_create(int device, ls1hip_ctx** out) {
+	if (!out) return LS1HIP_EINVAL;
+	*out = nullptr;
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev <= 0) {
+		g_create_err = std::string("no HIP device available: ") + hipGetErrorString(e);
+		return LS1HIP_ENODEV;
+	}
+	if (device < 0 || device >= ndev) {
+		g_create_err = "device index out of range";
+		return LS1HIP_EINVAL;
+	}
+	ls1hip_ctx* c = new ls1hip_ctx();
+	c->device = device;
+	memset(c->mol, 0, sizeof(c->mol));
+	memset(&c->frc, 0, sizeof(c->frc));
+	memset(&c->hs, 0, sizeof(c->hs));
+	memset(&c->h_ct, 0, sizeof(c->h_ct));
+	for (int i = 0; i < 27; ++i) c->nbr[i] = -1;
+	if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess ||
+		(e = hipMalloc((void**)&c->d_ct, sizeof(CompTable))) != hipSuccess ||
+		(e = hipMalloc((void**)&c->d_cnt, sizeof(DevCounters))) != hipSuccess ||
+		(e = hipHostMalloc((void**)&c->h_cnt, sizeof(DevCounters))) != hipSuccess ||
+		(e = hipMemset(c->d_cnt, 0, sizeof(DevCounters))) != hipSuccess) {
+		g_create_err = std::string("context setup failed: ") + hipGetErrorString(e);
+		delete c;
+		return LS1HIP_EHIP;
+	}
+	*out = c;
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_destroy(ls1hip_ctx* c) {
+	if (!c) return LS1HIP_OK;
+	hipSetDevice(c->device);
+	hipStreamSynchronize(c->stream);
+	free_mol(c);
+	free_cells(c);
+	dfree(c->d_ct);
+	dfree(c->d_cnt);
+	if (c->h_cnt) hipHostFree(c->h_cnt);
+	timer_free(c->t_force); timer_free(c->t_integrate); timer_free(c->t_rebin); timer_free(c->t_halo);
+	hipStreamDestroy(c->stream);
+	delete c;
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_set_option(ls1hip_ctx* c, const char* name, long v) {
+	if (!c || !name) return LS1HIP_EINVAL;
+	std::string n(name);
+	if (n == "force_kernel") {
+		REQUIRE(c, v >= 0 && v <= 2, "force_kernel must be 0..2");
+		c->opt_force_kernel = v;
+	} else if (n == "cells_in_cutoff") {
+		REQUIRE(c, v == 1 || v == 2, "cells_in_cutoff must be 1 or 2");
+		REQUIRE(c, !c->have_domain, "cells_in_cutoff must be set before ls1hip_set_domain");
+		c->opt_cic = v;
+	} else if (n == "compute_vi") {
+		c->opt_vi = v ? 1 : 0;
+	} else if (n == "deterministic") {
+		c->opt_det = v ? 1 : 0;
+	} else if (n == "count_pairs") {
+		c->opt_count_pairs = v ? 1 : 0;
+	} else {
+		FAIL(c, LS1HIP_EINVAL, "unknown option '%s'", name);
+	}
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_get_option(const ls1hip_ctx* c, const char* name, long* v) {
+	if (!c || !name || !v) return LS1HIP_EINVAL;
+	std::string n(name);
+	if (n == "force_kernel") *v = c->opt_force_kernel;
+	else if (n == "cells_in_cutoff") *v = c->opt_cic;
+	else if (n == "compute_vi") *v = c->opt_vi;
+	else if (n == "deterministic") *v = c->opt_det;
+	else if (n == "count_pairs") *v = c->opt_count_pairs;
+	else return LS1HIP_EINVAL;
+	return LS1HIP_OK;
+}
+
+// ---- model ---------------------------------------------------------------------------------------------------------
+extern "C" int ls1hip_set_components(ls1hip_ctx* c, int ncomp, const int* nlj, const int* nc, const int* nd,
+									 const int* nq, const double* lj, const double* ch, const double* dp,
+									 const double* qp, const double* mass, const double* I, const double* mix,
+									 double eps_rf, double rc, double rc_lj) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, ncomp >= 1 && ncomp <= MAXC, "ncomp must be in 1..%d", MAXC);
+	REQUIRE(c, nlj && nc && nd && nq && mass && I, "null component arrays");
+	REQUIRE(c, rc > 0. && rc_lj > 0., "cutoffs must be positive");
+	CompTable& t = c->h_ct;
+	memset(&t, 0, sizeof(t));
+	t.ncomp = ncomp;
+	int tl = 0, tc = 0, td = 0, tq = 0;
+	bool rot = false;
+	for (int k = 0; k < ncomp; ++k) {
+		REQUIRE(c, nlj[k] >= 0 && nc[k] >= 0 && nd[k] >= 0 && nq[k] >= 0, "negative site count");
+		t.nlj[k] = nlj[k]; t.nc[k] = nc[k]; t.nd[k] = nd[k]; t.nq[k] = nq[k];
+		t.olj[k] = tl; t.oc[k] = tc; t.od[k] = td; t.oq[k] = tq;
+		tl += nlj[k]; tc += nc[k]; td += nd[k]; tq += nq[k];
+		t.maxsites = std::max(t.maxsites, nlj[k] + nc[k] + nd[k] + nq[k]);
+		t.mass[k] = mass[k];
+		int rdof = 0;
+		for (int d = 0; d < 3; ++d) {
+			t.I[k][d] = I[3 * k + d];
+			t.invI[k][d] = (I[3 * k + d] != 0.) ? 1. / I[3 * k + d] : 0.;  // FullMolecule.h:88-101
+			if (I[3 * k + d] != 0.) ++rdof;
+		}
+		t.rotdof[k] = rdof;
+	}
+	REQUIRE(c, tl <= MAXS && tc <= MAXS && td <= MAXS && tq <= MAXS, "more than %d sites of one type", MAXS);
+	REQUIRE(c, (tl == 0 || lj) && (tc == 0 || ch) && (td == 0 || dp) && (tq == 0 || qp), "null site table");
+	REQUIRE(c, ncomp == 1 || mix, "mixing coefficients required for more than one component");
+	for (int k = 0; k < tl; ++k) {
+		const double* s = lj + (size_t)k * LS1HIP_LJ_STRIDE;
+		for (int d = 0; d < 3; ++d) {
+			t.ljpos[k][d] = s[d];
+			rot |= (s[d] != 0.);
+		}
+	}
+	for (int k = 0; k < tc; ++k) {
+		const double* s = ch + (size_t)k * LS1HIP_CH_STRIDE;
+		for (int d = 0; d < 3; ++d) {
+			t.chpos[k][d] = s[d];
+			rot |= (s[d] != 0.);
+		}
+		t.chq[k] = s[4];
+	}
+	for (int k = 0; k < td; ++k) {
+		const double* s = dp + (size_t)k * LS1HIP_DP_STRIDE;
+		for (int d = 0; d < 3; ++d) {
+			t.dppos[k][d] = s[d];
+			t.dpe[k][d] = s[3 + d];
+		}
+		t.dpmy[k] = s[6];
+		rot = true;
+	}
+	for (int k = 0; k < tq; ++k) {
+		const double* s = qp + (size_t)k * LS1HIP_QP_STRIDE;
+		for (int d = 0; d < 3; ++d) {
+			t.qppos[k][d] = s[d];
+			t.qpe[k][d] = s[3 + d];
+		}
+		t.qpQ[k] = s[6];
+		rot = true;
+	}
+	t.has_rot = rot ? 1 : 0;
+	t.ncenters = tl;
+	// LJ pair table: Comp2Param::initialize (Comp2Param.cpp:17-97) laid out like VectorizedCellProcessor's
+	// _eps_sig / _shift6 (VectorizedCellProcessor.cpp:41-83) on the global centre numbering.
+	int mixpos = 0;
+	for (int ci = 0; ci < ncomp; ++ci) {
+		for (int a = 0; a < nlj[ci]; ++a) {
+			const double* sa = lj + (size_t)(t.olj[ci] + a) * LS1HIP_LJ_STRIDE;
+			for (int b = 0; b < nlj[ci]; ++b) {
+				const double* sb = lj + (size_t)(t.olj[ci] + b) * LS1HIP_LJ_STRIDE;
+				const int k = (t.olj[ci] + a) * tl + (t.olj[ci] + b);
+				double sg = .5 * (sa[5] + sb[5]);
+				t.eps24[k] = 24. * sqrt(sa[4] * sb[4]);
+				t.sig2[k] = sg * sg;
+				t.shift6[k] = sa[6];
+			}
+		}
+		for (int cj = ci + 1; cj < ncomp; ++cj) {
+			const double xi = mix[2 * mixpos], eta = mix[2 * mixpos + 1];
+			++mixpos;
+			for (int a = 0; a < nlj[ci]; ++a) {
+				const double* sa = lj + (size_t)(t.olj[ci] + a) * LS1HIP_LJ_STRIDE;
+				for (int b = 0; b < nlj[cj]; ++b) {
+					const double* sb = lj + (size_t)(t.olj[cj] + b) * LS1HIP_LJ_STRIDE;
+					const double e24 = 24. * xi * sqrt(sa[4] * sb[4]);
+					double sg = eta * .5 * (sa[5] + sb[5]);
+					const double sg2 = sg * sg;
+					const double p2 = sg2 / (rc_lj * rc_lj);
+					const double p6 = p2 * p2 * p2;
+					const double sh = e24 * (p6 - p6 * p6);
+					const int kij = (t.olj[ci] + a) * tl + (t.olj[cj] + b);
+					const int kji = (t.olj[cj] + b) * tl + (t.olj[ci] + a);
+					t.eps24[kij] = t.eps24[kji] = e24;
+					t.sig2[kij] = t.sig2[kji] = sg2;
+					t.shift6[kij] = t.shift6[kji] = sh;
+				}
+			}
+		}
+	}
+	t.rc2 = rc * rc;
+	t.rclj2 = rc_lj * rc_lj;
+	t.epsRFInvrc3 = 2. * (eps_rf - 1.) / ((rc * rc * rc) * (2. * eps_rf + 1.));  // VectorizedCellProcessor.cpp:24
+	c->rc = rc;
+	c->rc_lj = rc_lj;
+	c->one_clj = (ncomp == 1 && tl == 1 && tc == 0 && td == 0 && tq == 0 && !rot && rc == rc_lj);
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipMemcpyAsync(c->d_ct, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	c->have_comp = true;
+	c->have_domain = false;  // the cell grid depends on the cutoff
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_get_lj_table(const ls1hip_ctx* c, int* ncenters, double* eps24, double* sig2, double* shift6) {
+	if (!c || !c->have_comp) return LS1HIP_EINVAL;
+	const int n = c->h_ct.ncenters;
+	if (ncenters) *ncenters = n;
+	if (eps24) memcpy(eps24, c->h_ct.eps24, sizeof(double) * n * n);
+	if (sig2) memcpy(sig2, c->h_ct.sig2, sizeof(double) * n * n);
+	if (shift6) memcpy(shift6, c->h_ct.shift6, sizeof(double) * n * n);
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_set_domain(ls1hip_ctx* c, const double global_len[3], const double box_min[3],
+								 const double box_max[3], int my_rank, const int neighbor_rank[27]) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, c->have_comp, "ls1hip_set_components must be called first");
+	REQUIRE(c, global_len && box_min && box_max && neighbor_rank, "null argument");
+	for (int d = 0; d < 3; ++d)
+		REQUIRE(c, box_max[d] > box_min[d] && box_min[d] >= 0. && box_max[d] <= global_len[d], "bad bounding box");
+	Grid g;
+	if (!grid_init(g, box_min, box_max, c->rc, (int)c->opt_cic))
+		FAIL(c, LS1HIP_EINVAL, "LinkedCells: region too small for the cutoff (or too many cells)");
+	c->g = g;
+	c->my_rank = my_rank;
+	c->has_remote = false;
+	for (int d = 0; d < 3; ++d) c->global_len[d] = global_len[d];
+	for (int sz = -1; sz <= 1; ++sz)
+		for (int sy = -1; sy <= 1; ++sy)
+			for (int sx = -1; sx <= 1; ++sx) {
+				const int dir = (sz + 1) * 9 + (sy + 1) * 3 + (sx + 1);
+				c->nbr[dir] = neighbor_rank[dir];
+				if (dir != 13 && neighbor_rank[dir] >= 0 && neighbor_rank[dir] != my_rank) c->has_remote = true;
+				const int s[3] = {sx, sy, sz};
+				for (int d = 0; d < 3; ++d) {
+					// a copy sent through the low face of the GLOBAL box reappears shifted by +L, through the high
+					// face by -L (DomainDecompBase.cpp:180-182,299-301); inside the global box no shift
+					double sh = 0.;
+					if (s[d] < 0 && box_min[d] == 0.) sh = global_len[d];
+					if (s[d] > 0 && box_max[d] == global_len[d]) sh = -global_len[d];
+					c->shift[dir][d] = sh;
+				}
+			}
+	c->nbr[13] = my_rank;
+	HIPCHK(c, hipSetDevice(c->device));
+	const size_t nc = (size_t)g.ncells;
+	if (nc > c->cells_alloc) {
+		free_cells(c);
+		int rc;
+		if ((rc = dalloc(c, &c->d_count, nc)) || (rc = dalloc(c, &c->d_cell_begin, nc)) ||
+			(rc = dalloc(c, &c->d_cell_end, nc)) || (rc = dalloc(c, &c->d_blocksum, nc / 1024 + 2)))
+			return rc;
+		c->cells_alloc = nc;
+	}
+	HIPCHK(c, hipMemsetAsync(c->d_count, 0, nc * sizeof(uint32_t), c->stream));
+	HIPCHK(c, hipMemsetAsync(c->d_cell_begin, 0, nc * sizeof(uint32_t), c->stream));
+	HIPCHK(c, hipMemsetAsync(c->d_cell_end, 0, nc * sizeof(uint32_t), c->stream));
+	c->have_domain = true;
+	c->binned = false;
+	c->halo_valid = false;
+	c->forces_valid = false;
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_get_grid(const ls1hip_ctx* c, int dims[3], double cell_len[3], int* halo_width) {
+	if (!c || !c->have_domain) return LS1HIP_EINVAL;
+	for (int d = 0; d < 3; ++d) {
+		if (dims) dims[d] = c->g.dims[d];
+		if (cell_len) cell_len[d] = c->g.clen[d];
+	}
+	if (halo_width) *halo_width = c->g.hw;
+	return LS1HIP_OK;
+}
+
+// ---- molecules -----------------------------------------------------------------------------------------------------
+static int alloc_mol(ls1hip_ctx* c, size_t n) {
+	const bool rot = c->h_ct.has_rot;
+	// capacities: owned molecules may grow by migration; halo copies from the geometry of the rc-shell
+	double vol = 1., vol_out = 1.;
+	for (int d = 0; d < 3; ++d) {
+		const double L = c->g.bmax[d] - c->g.bmin[d];
+		vol *= L;
+		vol_out *= L + 2. * c->rc;
+	}
+	const double dens = (double)n / vol;
+	size_t cap_real = (size_t)(n * (c->has_remote ? 1.25 : 1.0)) + 1024;
+	size_t cap_halo = (size_t)(dens * (vol_out - vol) * 1.6) + 4096;
+	cap_halo = std::min(cap_halo, 26 * n + 4096);
+	if (cap_real <= c->cap_real && cap_halo <= c->cap_halo) return 0;
+	free_mol(c);
+	const size_t tot = cap_real + cap_halo;
+	int rc = 0;
+	for (int k = 0; k < 2 && !rc; ++k) {
+		MolSoA& m = c->mol[k];
+		// set 0/1 both carry the halo segment (the rebin flips between them)
+		(rc = dalloc(c, &m.x, tot)) || (rc = dalloc(c, &m.y, tot)) || (rc = dalloc(c, &m.z, tot)) ||
+			(rc = dalloc(c, &m.vx, cap_real)) || (rc = dalloc(c, &m.vy, cap_real)) || (rc = dalloc(c, &m.vz, cap_real)) ||
+			(rc = dalloc(c, &m.id, tot)) || (rc = dalloc(c, &m.cid, tot));
+		if (!rc && rot)
+			(rc = dalloc(c, &m.q0, tot)) || (rc = dalloc(c, &m.q1, tot)) || (rc = dalloc(c, &m.q2, tot)) ||
+				(rc = dalloc(c, &m.q3, tot)) || (rc = dalloc(c, &m.Dx, cap_real)) || (rc = dalloc(c, &m.Dy, cap_real)) ||
+				(rc = dalloc(c, &m.Dz, cap_real));
+	}
+	if (rc) return rc;
+	ForceSoA& f = c->frc;
+	(rc = dalloc(c, &f.Fx, cap_real)) || (rc = dalloc(c, &f.Fy, cap_real)) || (rc = dalloc(c, &f.Fz, cap_real)) ||
+		(rc = dalloc(c, &f.Vix, cap_real)) || (rc = dalloc(c, &f.Viy, cap_real)) || (rc = dalloc(c, &f.Viz, cap_real));
+	if (!rc && rot) (rc = dalloc(c, &f.Mx, cap_real)) || (rc = dalloc(c, &f.My, cap_real)) || (rc = dalloc(c, &f.Mz, cap_real));
+	if (rc) return rc;
+	HaloStage& h = c->hs;
+	(rc = dalloc(c, &h.x, cap_halo)) || (rc = dalloc(c, &h.y, cap_halo)) || (rc = dalloc(c, &h.z, cap_halo)) ||
+		(rc = dalloc(c, &h.id, cap_halo)) || (rc = dalloc(c, &h.cid, cap_halo)) || (rc = dalloc(c, &h.key, cap_halo)) ||
+		(rc = dalloc(c, &h.rank, cap_halo));
+	if (!rc && rot)
+		(rc = dalloc(c, &h.q0, cap_halo)) || (rc = dalloc(c, &h.q1, cap_halo)) || (rc = dalloc(c, &h.q2, cap_halo)) ||
+			(rc = dalloc(c, &h.q3, cap_halo));
+	if (rc) return rc;
+	(rc = dalloc(c, &c->d_key, cap_real)) || (rc = dalloc(c, &c->d_rank, cap_real)) ||
+		(rc = dalloc(c, &c->d_perm, std::max(cap_real, cap_halo))) || (rc = dalloc(c, &c->d_ckey, cap_real));
+	if (rc) return rc;
+	c->partials_cap = cap_real / 64 + 16;
+	if ((rc = dalloc(c, &c->d_partials, c->partials_cap * 4))) return rc;
+	// export slices per remote direction, sized from the geometry of the region that feeds the direction
+	uint32_t offL = 0, offH = 0;
+	for (int sz = -1; sz <= 1; ++sz)
+		for (int sy = -1; sy <= 1; ++sy)
+			for (int sx = -1; sx <= 1; ++sx) {
+				const int dir = (sz + 1) * 9 + (sy + 1) * 3 + (sx + 1);
+				c->exp_off_leave[dir] = offL;
+				c->exp_off_halo[dir] = offH;
+				if (dir == 13 || c->nbr[dir] < 0 || c->nbr[dir] == c->my_rank) continue;
+				const int s[3] = {sx, sy, sz};
+				double v = 1.;
+				for (int d = 0; d < 3; ++d) v *= (s[d] != 0) ? c->rc : (c->g.bmax[d] - c->g.bmin[d]);
+				const uint32_t cap = (uint32_t)(dens * v * 1.6) + 2048;
+				offH += cap;
+				offL += cap / 2 + 1024;
+			}
+	c->exp_off_leave[27] = offL;
+	c->exp_off_halo[27] = offH;
+	if ((rc = dalloc(c, &c->d_exp_leave, (size_t)offL * LS1HIP_LEAVING_DOUBLES)) ||
+		(rc = dalloc(c, &c->d_exp_halo, (size_t)offH * LS1HIP_HALO_DOUBLES)))
+		return rc;
+	c->cap_real = cap_real;
+	c->cap_halo = cap_halo;
+	return 0;
+}
+
+template <class T>
+static int h2d(ls1hip_ctx* c, T* dst, const std::vector<T>& src) {
+	if (src.empty()) return 0;
+	HIPCHK(c, hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+	return 0;
+}
+
+extern "C" int ls1hip_upload(ls1hip_ctx* c, size_t n, const uint64_t* id, const int32_t* cid, const double* r,
+							 const double* v, const double* q, const double* D) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, c->have_domain, "ls1hip_set_domain must be called first");
+	REQUIRE(c, n == 0 || (id && r && v), "null molecule arrays");
+	REQUIRE(c, n < 0x7fff0000ull, "too many molecules for 32-bit indices");
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	int rc = alloc_mol(c, n);
+	if (rc) return rc;
+	const bool rot = c->h_ct.has_rot;
+	for (size_t i = 0; i < n; ++i) {
+		for (int d = 0; d < 3; ++d)
+			REQUIRE(c, r[3 * i + d] >= c->g.bmin[d] && r[3 * i + d] < c->g.bmax[d],
+					"molecule %zu lies outside the bounding box of this rank", i);
+		REQUIRE(c, !cid || (cid[i] >= 0 && cid[i] < c->h_ct.ncomp), "molecule %zu has a wrong component id", i);
+	}
+	c->cur = 0;
+	MolSoA& m = c->mol[0];
+	std::vector<double> t0(n), t1(n), t2(n);
+	auto put3 = [&](const double* src, int stride, int o, double* d0, double* d1, double* d2) -> int {
+		for (size_t i = 0; i < n; ++i) {
+			t0[i] = src[stride * i + o];
+			t1[i] = src[stride * i + o + 1];
+			t2[i] = src[stride * i + o + 2];
+		}
+		int e;
+		if ((e = h2d(c, d0, t0)) || (e = h2d(c, d1, t1)) || (e = h2d(c, d2, t2))) return e;
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		return 0;
+	};
+	if (n) {
+		if ((rc = put3(r, 3, 0, m.x, m.y, m.z)) || (rc = put3(v, 3, 0, m.vx, m.vy, m.vz))) return rc;
+		if (rot) {
+			std::vector<double> qq(4 * n), dd(3 * n, 0.);
+			for (size_t i = 0; i < n; ++i) {
+				if (q) for (int k = 0; k < 4; ++k) qq[4 * i + k] = q[4 * i + k];
+				else { qq[4 * i] = 1.; qq[4 * i + 1] = qq[4 * i + 2] = qq[4 * i + 3] = 0.; }
+			}
+			if (D) dd.assign(D, D + 3 * n);
+			for (size_t i = 0; i < n; ++i) t0[i] = qq[4 * i];
+			if ((rc = h2d(c, m.q0, t0))) return rc;
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			if ((rc = put3(qq.data(), 4, 1, m.q1, m.q2, m.q3)) || (rc = put3(dd.data(), 3, 0, m.Dx, m.Dy, m.Dz))) return rc;
+		}
+		std::vector<int32_t> cc(n, 0);
+		if (cid) cc.assign(cid, cid + n);
+		HIPCHK(c, hipMemcpyAsync(m.id, id, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+		HIPCHK(c, hipMemcpyAsync(m.cid, cc.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+	}
+	// forces start at zero (a freshly read phase space has F = M = 0: FullMolecule.cpp:44-45)
+	HIPCHK(c, hipMemsetAsync(c->frc.Fx, 0, c->cap_real * sizeof(double), c->stream));
+	HIPCHK(c, hipMemsetAsync(c->frc.Fy, 0, c->cap_real * sizeof(double), c->stream));
+	HIPCHK(c, hipMemsetAsync(c->frc.Fz, 0, c->cap_real * sizeof(double), c->stream));
+	if (rot) {
+		HIPCHK(c, hipMemsetAsync(c->frc.Mx, 0, c->cap_real * sizeof(double), c->stream));
+		HIPCHK(c, hipMemsetAsync(c->frc.My, 0, c->cap_real * sizeof(double), c->stream));
+		HIPCHK(c, hipMemsetAsync(c->frc.Mz, 0, c->cap_real * sizeof(double), c->stream));
+	}
+	HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(DevCounters), c->stream));
+	c->h_cnt->n_real = (uint32_t)n;
+	HIPCHK(c, hipMemcpyAsync(&c->d_cnt->n_real, &c->h_cnt->n_real, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	c->n_real = n;
+	c->n_halo = 0;
+	c->binned = false;
+	c->halo_valid = false;
+	c->forces_valid = false;
+	return LS1HIP_OK;
+}
+
+static int sync_counters(ls1hip_ctx* c) {
+	HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->d_cnt, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	c->n_halo = c->h_cnt->n_halo;
+	if (c->h_cnt->err_overflow)
+		FAIL(c, LS1HIP_ENOMEM, "device buffer overflow (%u records dropped): halo/export capacity exceeded", c->h_cnt->err_overflow);
+	if (c->h_cnt->err_lost)
+		FAIL(c, LS1HIP_ELOST, "%u molecule(s) left the halo region of this rank", c->h_cnt->err_lost);
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_count(const ls1hip_ctx* c, size_t* n_owned, size_t* n_halo) {
+	if (!c) return LS1HIP_EINVAL;
+	if (n_owned) *n_owned = c->n_real;
+	if (n_halo) *n_halo = c->n_halo;
+	return LS1HIP_OK;
+}
+
+// ---- step pieces ---------------------------------------------------------------------------------------------------
+static RebinArgs rebin_args(ls1hip_ctx* c, uint32_t n_in) {
+	RebinArgs a;
+	a.g = c->g;
+	a.src = c->mol[c->cur];
+	a.dst = c->mol[c->cur ^ 1];
+	a.has_rot = c->h_ct.has_rot;
+	a.key = c->d_key; a.rank = c->d_rank; a.perm = c->d_perm; a.ckey = c->d_ckey;
+	a.count = c->d_count; a.cell_begin = c->d_cell_begin; a.cell_end = c->d_cell_end; a.blocksum = c->d_blocksum;
+	a.cnt = c->d_cnt;
+	a.n_in = n_in;
+	memcpy(a.nbr, c->nbr, sizeof(a.nbr));
+	a.my_rank = c->my_rank;
+	memcpy(a.shift, c->shift, sizeof(a.shift));
+	a.exp_leave = c->d_exp_leave;
+	memcpy(a.exp_off, c->exp_off_leave, sizeof(a.exp_off));
+	a.cap_real = (uint32_t)c->cap_real;
+	a.deterministic = (int)c->opt_det;
+	return a;
+}
+
+static HaloArgs halo_args(ls1hip_ctx* c) {
+	HaloArgs a;
+	a.g = c->g;
+	a.mol = c->mol[c->cur];
+	a.hs = c->hs;
+	a.has_rot = c->h_ct.has_rot;
+	a.perm = c->d_perm; a.count = c->d_count; a.cell_begin = c->d_cell_begin; a.cell_end = c->d_cell_end;
+	a.blocksum = c->d_blocksum;
+	a.cnt = c->d_cnt;
+	a.n_real_cap = (uint32_t)c->n_real;
+	a.cap_halo = (uint32_t)c->cap_halo;
+	memcpy(a.nbr, c->nbr, sizeof(a.nbr));
+	a.my_rank = c->my_rank;
+	memcpy(a.shift, c->shift, sizeof(a.shift));
+	a.rc = c->rc;
+	a.exp_halo = c->d_exp_halo;
+	memcpy(a.exp_off, c->exp_off_halo, sizeof(a.exp_off));
+	a.deterministic = (int)c->opt_det;
+	return a;
+}
+
+static int do_rebin_finish(ls1hip_ctx* c, uint32_t n_in) {
+	RebinArgs a = rebin_args(c, n_in);
+	launch_rebin_sort_gather(a, c->stream);
+	c->cur ^= 1;
+	c->binned = true;
+	c->halo_valid = false;
+	c->forces_valid = false;
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_rebin(ls1hip_ctx* c) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, c->have_domain && c->cap_real, "no molecules uploaded");
+	HIPCHK(c, hipSetDevice(c->device));
+	TimedScope ts(c, c->t_rebin);
+	RebinArgs a = rebin_args(c, (uint32_t)c->n_real);
+	launch_rebin_classify(a, c->stream);
+	c->pending_in = (uint32_t)c->n_real;
+	if (!c->has_remote) return do_rebin_finish(c, (uint32_t)c->n_real);
+	c->binned = false;
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_halo(ls1hip_ctx* c) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, c->binned, "ls1hip_rebin (and import_done(0) on multi-rank domains) must precede ls1hip_halo");
+	HIPCHK(c, hipSetDevice(c->device));
+	TimedScope ts(c, c->t_halo);
+	HaloArgs a = halo_args(c);
+	launch_halo_generate(a, c->stream);
+	if (!c->has_remote) {
+		launch_halo_finalize(a, c->stream);
+		c->halo_valid = true;
+	}
+	c->forces_valid = false;
+	return LS1HIP_OK;
+}
+
+static int launch_forces(ls1hip_ctx* c, int which) {
+	ForceParams P;
+	memset(&P, 0, sizeof(P));
+	const MolSoA& m = c->mol[c->cur];
+	P.g = c->g;
+	P.x = m.x; P.y = m.y; P.z = m.z; P.q0 = m.q0; P.q1 = m.q1; P.q2 = m.q2; P.q3 = m.q3;
+	P.cid = m.cid;
+	P.cell_begin = c->d_cell_begin; P.cell_end = c->d_cell_end; P.ckey = c->d_ckey;
+	P.Fx = c->frc.Fx; P.Fy = c->frc.Fy; P.Fz = c->frc.Fz; P.Mx = c->frc.Mx; P.My = c->frc.My; P.Mz = c->frc.Mz;
+	P.Vix = c->frc.Vix; P.Viy = c->frc.Viy; P.Viz = c->frc.Viz;
+	P.ct = c->d_ct;
+	P.cnt = c->d_cnt;
+	P.partials = c->d_partials;
+	P.n_real_cap = (uint32_t)c->n_real;
+	P.which = which;
+	P.count_pairs = (int)c->opt_count_pairs;
+	P.eps24 = c->h_ct.eps24[0];
+	P.sig2 = c->h_ct.sig2[0];
+	P.shift6 = c->h_ct.shift6[0];
+	P.rc2 = c->h_ct.rc2;
+	uint32_t nblocks = 0;
+	if (which == 0 || which == 1) launch_clear_macro(c->d_cnt, c->stream);
+	bool done = false;
+	if (c->one_clj && c->opt_force_kernel != LS1HIP_FK_GENERIC && !c->opt_vi && !c->opt_count_pairs) {
+		done = launch_force_lj(P, c->stream, &nblocks, c->d_partials, c->partials_cap);
+	}
+	if (!done) {
+		if (c->opt_force_kernel == LS1HIP_FK_LDS_LIST && !c->one_clj)
+			FAIL(c, LS1HIP_EINVAL, "force_kernel=LDS_LIST supports single-centre LJ components only");
+		launch_force_generic(P, c->one_clj, c->opt_vi != 0, c->h_ct.has_rot != 0, c->stream, &nblocks);
+	}
+	launch_force_reduce(c->d_cnt, c->d_partials, nblocks, c->stream);
+	return LS1HIP_OK;
+}
+
+static void macro_to_upot_virial(const DevCounters* h, double* upot, double* virial) {
+	// VectorizedCellProcessor::endTraversal, VectorizedCellProcessor.cpp:155-156
+	if (upot) *upot = h->macro[0] / 6.0 + h->macro[1] + h->macro[2];
+	if (virial) *virial = h->macro[3] + 3.0 * h->macro[2];
+}
+
+extern "C" int ls1hip_forces(ls1hip_ctx* c, int which, double* upot, double* virial) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, which >= 0 && which <= 2, "which must be 0, 1 or 2");
+	REQUIRE(c, c->binned, "molecules are not binned (call ls1hip_rebin)");
+	REQUIRE(c, which == 1 || c->halo_valid, "halo not populated (call ls1hip_halo / import_done(1))");
+	HIPCHK(c, hipSetDevice(c->device));
+	{
+		TimedScope ts(c, c->t_force);
+		int rc = launch_forces(c, which);
+		if (rc) return rc;
+	}
+	if (which != 1) c->forces_valid = true;
+	if (upot || virial) {
+		int rc = sync_counters(c);
+		if (rc) return rc;
+		macro_to_upot_virial(c->h_cnt, upot, virial);
+	}
+	return LS1HIP_OK;
+}
+
+static IntegArgs integ_args(ls1hip_ctx* c, double dt) {
+	IntegArgs a;
+	a.mol = c->mol[c->cur];
+	a.frc = c->frc;
+	a.ct = c->d_ct;
+	a.cnt = c->d_cnt;
+	a.partials = c->d_partials;
+	a.n_cap = (uint32_t)c->n_real;
+	a.has_rot = c->h_ct.has_rot;
+	a.dt = dt;
+	return a;
+}
+
+extern "C" int ls1hip_kick_drift(ls1hip_ctx* c, double dt) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, c->cap_real, "no molecules uploaded");
+	HIPCHK(c, hipSetDevice(c->device));
+	TimedScope ts(c, c->t_integrate);
+	launch_kick_drift(integ_args(c, dt), c->stream);
+	c->binned = false;
+	c->halo_valid = false;
+	c->forces_valid = false;
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_kick(ls1hip_ctx* c, double dt_half, double* summv2, double* sumIw2, uint64_t* n,
+						   uint64_t* rot_dof) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, c->forces_valid, "forces are not valid (call ls1hip_forces)");
+	HIPCHK(c, hipSetDevice(c->device));
+	{
+		TimedScope ts(c, c->t_integrate);
+		uint32_t nb = 0;
+		launch_kick(integ_args(c, dt_half), c->stream, &nb);
+		launch_kin_reduce(c->d_cnt, c->d_partials, nb, c->stream);
+	}
+	if (summv2 || sumIw2 || n || rot_dof) {
+		int rc = sync_counters(c);
+		if (rc) return rc;
+		if (summv2) *summv2 = c->h_cnt->kin[0];
+		if (sumIw2) *sumIw2 = c->h_cnt->kin[1];
+		if (n) *n = c->h_cnt->kin_n;
+		if (rot_dof) *rot_dof = c->h_cnt->kin_rotdof;
+	}
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double* out6) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, !c->has_remote, "ls1hip_run drives single-rank domains only (use the piecewise calls with a transport)");
+	REQUIRE(c, c->forces_valid, "initial forces required (rebin, halo, forces) before ls1hip_run");
+	HIPCHK(c, hipSetDevice(c->device));
+	for (unsigned long s = 0; s < nsteps; ++s) {
+		int rc;
+		if ((rc = ls1hip_kick_drift(c, dt)) || (rc = ls1hip_rebin(c)) || (rc = ls1hip_halo(c)) ||
+			(rc = ls1hip_forces(c, 0, nullptr, nullptr)) || (rc = ls1hip_kick(c, 0.5 * dt, nullptr, nullptr, nullptr, nullptr)))
+			return rc;
+	}
+	int rc = sync_counters(c);
+	if (rc) return rc;
+	if (out6) {
+		macro_to_upot_virial(c->h_cnt, &out6[0], &out6[1]);
+		out6[2] = c->h_cnt->kin[0];
+		out6[3] = c->h_cnt->kin[1];
+		out6[4] = (double)c->h_cnt->kin_n;
+		out6[5] = (double)c->h_cnt->kin_rotdof;
+	}
+	return LS1HIP_OK;
+}
+
+// ---- downloads -----------------------------------------------------------------------------------------------------
+static int d2h3(ls1hip_ctx* c, size_t n, const double* a, const double* b, const double* d, double* out, int stride, int o) {
+	std::vector<double> t(n);
+	const double* src[3] = {a, b, d};
+	for (int k = 0; k < 3; ++k) {
+		if (src[k]) {
+			HIPCHK(c, hipMemcpy(t.data(), src[k], n * sizeof(double), hipMemcpyDeviceToHost));
+			for (size_t i = 0; i < n; ++i) out[stride * i + o + k] = t[i];
+		} else {
+			for (size_t i = 0; i < n; ++i) out[stride * i + o + k] = 0.;
+		}
+	}
+	return 0;
+}
+
+extern "C" int ls1hip_download_state(ls1hip_ctx* c, size_t cap, uint64_t* id, int32_t* cid, double* r, double* v,
+									 double* q, double* D) {
+	if (!c) return LS1HIP_EINVAL;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	const size_t n = c->n_real;
+	REQUIRE(c, cap >= n, "buffer too small: %zu < %zu", cap, n);
+	if (n == 0) return LS1HIP_OK;
+	const MolSoA& m = c->mol[c->cur];
+	int rc;
+	if (id) HIPCHK(c, hipMemcpy(id, m.id, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+	if (cid) HIPCHK(c, hipMemcpy(cid, m.cid, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+	if (r && (rc = d2h3(c, n, m.x, m.y, m.z, r, 3, 0))) return rc;
+	if (v && (rc = d2h3(c, n, m.vx, m.vy, m.vz, v, 3, 0))) return rc;
+	if (q) {
+		if (c->h_ct.has_rot) {
+			std::vector<double> t(n);
+			HIPCHK(c, hipMemcpy(t.data(), m.q0, n * sizeof(double), hipMemcpyDeviceToHost));
+			for (size_t i = 0; i < n; ++i) q[4 * i] = t[i];
+			if ((rc = d2h3(c, n, m.q1, m.q2, m.q3, q, 4, 1))) return rc;
+		} else {
+			for (size_t i = 0; i < n; ++i) {
+				q[4 * i] = 1.;
+				q[4 * i + 1] = q[4 * i + 2] = q[4 * i + 3] = 0.;
+			}
+		}
+	}
+	if (D && (rc = d2h3(c, n, c->h_ct.has_rot ? m.Dx : nullptr, c->h_ct.has_rot ? m.Dy : nullptr,
+						c->h_ct.has_rot ? m.Dz : nullptr, D, 3, 0)))
+		return rc;
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_download_forces(ls1hip_ctx* c, size_t cap, double* F, double* M, double* Vi) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, c->forces_valid, "forces are not valid");
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	const size_t n = c->n_real;
+	REQUIRE(c, cap >= n, "buffer too small: %zu < %zu", cap, n);
+	if (n == 0) return LS1HIP_OK;
+	int rc;
+	const bool rot = c->h_ct.has_rot;
+	if (F && (rc = d2h3(c, n, c->frc.Fx, c->frc.Fy, c->frc.Fz, F, 3, 0))) return rc;
+	if (M && (rc = d2h3(c, n, rot ? c->frc.Mx : nullptr, rot ? c->frc.My : nullptr, rot ? c->frc.Mz : nullptr, M, 3, 0)))
+		return rc;
+	if (Vi) {
+		REQUIRE(c, c->opt_vi, "per-molecule virial was not computed (set option compute_vi=1 before ls1hip_forces)");
+		if ((rc = d2h3(c, n, c->frc.Vix, c->frc.Viy, c->frc.Viz, Vi, 3, 0))) return rc;
+	}
+	return LS1HIP_OK;
+}
+
+// ---- multi-GPU plumbing --------------------------------------------------------------------------------------------
+extern "C" int ls1hip_export_counts(ls1hip_ctx* c, int kind, uint64_t counts[27]) {
+	if (!c || !counts) return LS1HIP_EINVAL;
+	REQUIRE(c, kind == 0 || kind == 1, "kind must be 0 or 1");
+	HIPCHK(c, hipSetDevice(c->device));
+	int rc = sync_counters(c);
+	if (rc) return rc;
+	for (int d = 0; d < 27; ++d) counts[d] = kind == 0 ? c->h_cnt->exp_leave[d] : c->h_cnt->exp_halo[d];
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_export_pack(ls1hip_ctx* c, int kind, int dir, void* dev_buf, size_t cap) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, (kind == 0 || kind == 1) && dir >= 0 && dir < 27 && dev_buf, "bad argument");
+	HIPCHK(c, hipSetDevice(c->device));
+	const uint32_t n = kind == 0 ? c->h_cnt->exp_leave[dir] : c->h_cnt->exp_halo[dir];
+	REQUIRE(c, cap >= n, "export buffer too small: %zu < %u records", cap, n);
+	const int w = kind == 0 ? LS1HIP_LEAVING_DOUBLES : LS1HIP_HALO_DOUBLES;
+	const double* src = kind == 0 ? c->d_exp_leave + (size_t)c->exp_off_leave[dir] * w
+								  : c->d_exp_halo + (size_t)c->exp_off_halo[dir] * w;
+	launch_pack_copy((double*)dev_buf, src, n * w, c->stream);
+	HIPCHK(c, hipStreamSynchronize(c->stream));  // the transport runs on its own stream
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_import(ls1hip_ctx* c, int kind, const void* dev_buf, size_t n) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, kind == 0 || kind == 1, "kind must be 0 or 1");
+	REQUIRE(c, n == 0 || dev_buf, "null buffer");
+	HIPCHK(c, hipSetDevice(c->device));
+	if (kind == 0) {
+		REQUIRE(c, c->pending_in + n <= c->cap_real, "owned-molecule capacity exceeded by immigration");
+		RebinArgs a = rebin_args(c, c->pending_in);
+		launch_leave_import(a, (const double*)dev_buf, (uint32_t)n, c->pending_in, c->stream);
+		c->pending_in += (uint32_t)n;
+	} else {
+		HaloArgs a = halo_args(c);
+		launch_halo_import(a, (const double*)dev_buf, (uint32_t)n, c->stream);
+	}
+	HIPCHK(c, hipStreamSynchronize(c->stream));  // dev_buf may be reused by the caller
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_import_done(ls1hip_ctx* c, int kind) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, kind == 0 || kind == 1, "kind must be 0 or 1");
+	HIPCHK(c, hipSetDevice(c->device));
+	if (kind == 0) {
+		int rc = do_rebin_finish(c, c->pending_in);
+		if (rc) return rc;
+		if ((rc = sync_counters(c))) return rc;
+		c->n_real = c->h_cnt->n_real;
+	} else {
+		REQUIRE(c, c->binned, "halo import before rebin");
+		HaloArgs a = halo_args(c);
+		launch_halo_finalize(a, c->stream);
+		c->halo_valid = true;
+	}
+	return LS1HIP_OK;
+}
+
+// ---- measurement ---------------------------------------------------------------------------------------------------
+static Timer* timer_by_name(ls1hip_ctx* c, const char* name) {
+	std::string n(name ? name : "");
+	if (n == "force") return &c->t_force;
+	if (n == "integrate") return &c->t_integrate;
+	if (n == "rebin") return &c->t_rebin;
+	if (n == "halo") return &c->t_halo;
+	return nullptr;
+}
+
+extern "C" int ls1hip_timing(ls1hip_ctx* c, const char* name, double* total_ms, uint64_t* launches) {
+	if (!c) return LS1HIP_EINVAL;
+	Timer* t = timer_by_name(c, name);
+	REQUIRE(c, t, "unknown timer '%s'", name ? name : "(null)");
+	HIPCHK(c, hipSetDevice(c->device));
+	timer_collect(*t);
+	if (total_ms) *total_ms = t->total_ms;
+	if (launches) *launches = t->launches;
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_timing_reset(ls1hip_ctx* c) {
+	if (!c) return LS1HIP_EINVAL;
+	for (Timer* t : {&c->t_force, &c->t_integrate, &c->t_rebin, &c->t_halo}) {
+		timer_collect(*t);
+		t->total_ms = 0;
+		t->launches = 0;
+	}
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_timing_enable(ls1hip_ctx* c, int on) {
+	if (!c) return LS1HIP_EINVAL;
+	c->timing_on = on != 0;
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_pair_stats(ls1hip_ctx* c, uint64_t* dist_checks, uint64_t* pairs_in_range) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, c->opt_count_pairs, "option count_pairs=1 required");
+	int rc = sync_counters(c);
+	if (rc) return rc;
+	if (dist_checks) *dist_checks = c->h_cnt->dist_checks;
+	if (pairs_in_range) *pairs_in_range = c->h_cnt->pairs_in_range;
+	return LS1HIP_OK;
+}
+
+// ---- seam A --------------------------------------------------------------------------------------------------------
+extern "C" int ls1hip_soa_forces(ls1hip_ctx* c, const int cell_dims[3], const uint32_t* cell_start, size_t n,
+								 const double* r, const double* q, const int32_t* cid, double* F, double* M, double* Vi,
+								 double* upot, double* virial) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, c->have_comp, "ls1hip_set_components must be called first");
+	REQUIRE(c, cell_dims && cell_start && (n == 0 || r), "null argument");
+	REQUIRE(c, cell_dims[0] >= 3 && cell_dims[1] >= 3 && cell_dims[2] >= 3, "cell grid must include the halo layer");
+	const size_t ncells = (size_t)cell_dims[0] * cell_dims[1] * cell_dims[2];
+	REQUIRE(c, cell_start[ncells] == n, "cell_start[ncells] must equal n");
+	HIPCHK(c, hipSetDevice(c->device));
+	const bool rot = c->h_ct.has_rot;
+	std::vector<double> hx(n), hy(n), hz(n), h0, h1, h2, h3;
+	std::vector<int32_t> hc(n, 0);
+	std::vector<uint32_t> hkey(n), hb(ncells), he(ncells);
+	for (size_t i = 0; i < n; ++i) {
+		hx[i] = r[3 * i];
+		hy[i] = r[3 * i + 1];
+		hz[i] = r[3 * i + 2];
+		if (cid) hc[i] = cid[i];
+	}
+	if (rot) {
+		h0.resize(n); h1.resize(n); h2.resize(n); h3.resize(n);
+		for (size_t i = 0; i < n; ++i) {
+			h0[i] = q ? q[4 * i] : 1.;
+			h1[i] = q ? q[4 * i + 1] : 0.;
+			h2[i] = q ? q[4 * i + 2] : 0.;
+			h3[i] = q ? q[4 * i + 3] : 0.;
+		}
+	}
+	for (size_t cc = 0; cc < ncells; ++cc) {
+		REQUIRE(c, cell_start[cc] <= cell_start[cc + 1], "cell_start must be non-decreasing");
+		hb[cc] = cell_start[cc];
+		he[cc] = cell_start[cc + 1];
+		for (uint32_t p = cell_start[cc]; p < cell_start[cc + 1]; ++p) hkey[p] = (uint32_t)cc;
+	}
+	double *dx = nullptr, *dy = nullptr, *dz = nullptr, *d0 = nullptr, *d1 = nullptr, *d2 = nullptr, *d3 = nullptr;
+	double *fx = nullptr, *fy = nullptr, *fz = nullptr, *mx = nullptr, *my = nullptr, *mz = nullptr, *vx = nullptr,
+		   *vy = nullptr, *vz = nullptr, *part = nullptr;
+	int32_t* dc = nullptr;
+	uint32_t *dk = nullptr, *db = nullptr, *de = nullptr;
+	int rc = 0;
+	const size_t npart = n / 64 + 16;
+	(rc = dalloc(c, &dx, n)) || (rc = dalloc(c, &dy, n)) || (rc = dalloc(c, &dz, n)) || (rc = dalloc(c, &dc, n)) ||
+		(rc = dalloc(c, &dk, n)) || (rc = dalloc(c, &db, ncells)) || (rc = dalloc(c, &de, ncells)) ||
+		(rc = dalloc(c, &fx, n)) || (rc = dalloc(c, &fy, n)) || (rc = dalloc(c, &fz, n)) || (rc = dalloc(c, &vx, n)) ||
+		(rc = dalloc(c, &vy, n)) || (rc = dalloc(c, &vz, n)) || (rc = dalloc(c, &part, npart * 4));
+	if (!rc && rot)
+		(rc = dalloc(c, &d0, n)) || (rc = dalloc(c, &d1, n)) || (rc = dalloc(c, &d2, n)) || (rc = dalloc(c, &d3, n)) ||
+			(rc = dalloc(c, &mx, n)) || (rc = dalloc(c, &my, n)) || (rc = dalloc(c, &mz, n));
+	auto cleanup = [&]() {
+		dfree(dx); dfree(dy); dfree(dz); dfree(d0); dfree(d1); dfree(d2); dfree(d3); dfree(dc); dfree(dk); dfree(db);
+		dfree(de); dfree(fx); dfree(fy); dfree(fz); dfree(mx); dfree(my); dfree(mz); dfree(vx); dfree(vy); dfree(vz);
+		dfree(part);
+	};
+	if (rc) {
+		cleanup();
+		return rc;
+	}
+	auto up = [&](void* d, const void* h, size_t bytes) { return bytes ? hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) : hipSuccess; };
+	hipError_t e = hipSuccess;
+	if ((e = up(dx, hx.data(), n * 8)) || (e = up(dy, hy.data(), n * 8)) || (e = up(dz, hz.data(), n * 8)) ||
+		(e = up(dc, hc.data(), n * 4)) || (e = up(dk, hkey.data(), n * 4)) || (e = up(db, hb.data(), ncells * 4)) ||
+		(e = up(de, he.data(), ncells * 4)) ||
+		(rot && ((e = up(d0, h0.data(), n * 8)) || (e = up(d1, h1.data(), n * 8)) || (e = up(d2, h2.data(), n * 8)) ||
+				 (e = up(d3, h3.data(), n * 8))))) {
+		cleanup();
+		FAIL(c, LS1HIP_EHIP, "upload failed: %s", hipGetErrorString(e));
+	}
+	for (double* z : {fx, fy, fz, vx, vy, vz}) hipMemsetAsync(z, 0, n * 8, c->stream);
+	if (rot) for (double* z : {mx, my, mz}) hipMemsetAsync(z, 0, n * 8, c->stream);
+	ForceParams P;
+	memset(&P, 0, sizeof(P));
+	P.g.dims[0] = cell_dims[0]; P.g.dims[1] = cell_dims[1]; P.g.dims[2] = cell_dims[2];
+	P.g.hw = 1;
+	P.g.ncells = (int)ncells;
+	for (int d = 0; d < 3; ++d) P.g.box[d] = cell_dims[d] - 2;
+	P.x = dx; P.y = dy; P.z = dz; P.q0 = d0; P.q1 = d1; P.q2 = d2; P.q3 = d3;
+	P.cid = dc;
+	P.cell_begin = db; P.cell_end = de; P.ckey = dk;
+	P.Fx = fx; P.Fy = fy; P.Fz = fz; P.Mx = mx; P.My = my; P.Mz = mz; P.Vix = vx; P.Viy = vy; P.Viz = vz;
+	P.ct = c->d_ct;
+	P.cnt = c->d_cnt;
+	P.partials = part;
+	P.n_real_cap = (uint32_t)n;
+	P.n_fixed = (uint32_t)n;
+	P.which = 3;
+	P.eps24 = c->h_ct.eps24[0]; P.sig2 = c->h_ct.sig2[0]; P.shift6 = c->h_ct.shift6[0]; P.rc2 = c->h_ct.rc2;
+	uint32_t nblocks = 0;
+	launch_clear_macro(c->d_cnt, c->stream);
+	if (n) {
+		launch_force_generic(P, c->one_clj, true, rot, c->stream, &nblocks);
+		launch_force_reduce(c->d_cnt, part, nblocks, c->stream);
+	}
+	rc = sync_counters(c);
+	if (!rc) {
+		macro_to_upot_virial(c->h_cnt, upot, virial);
+		if (F) rc = d2h3(c, n, fx, fy, fz, F, 3, 0);
+		if (!rc && M) rc = d2h3(c, n, rot ? mx : nullptr, rot ? my : nullptr, rot ? mz : nullptr, M, 3, 0);
+		if (!rc && Vi) rc = d2h3(c, n, vx, vy, vz, Vi, 3, 0);
+	}
+	cleanup();
+	return rc;
+}

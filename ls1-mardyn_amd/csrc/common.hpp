@@ -1,0 +1,190 @@
+// common.hpp — context, device-resident data layout and kernel launch interface of libls1hip.
+//
+// Data layout in HBM (design stance of SURVEY.md §7: device-resident, cell-sorted global SoA):
+//   owned molecules  [0, n_real)                sorted by inner/boundary cell (x-fastest linear cell index),
+//   halo copies      [n_real, n_real + n_halo)  sorted by halo cell,
+// one FP64 array per coordinate (x,y,z | vx,vy,vz | q0..q3 | Dx,Dy,Dz | Fx.. | Mx.. | Vix..), u64 id, i32 cid.
+// cell_begin[c] / cell_end[c] give the slice of every cell of the full grid (incl. halo cells) in that index
+// space.  Keeping the halo copies in their own segment is what lets the inner-cell force launch run while the
+// halo segment is still being exchanged/sorted (the reference's NonBlockingMPIMultiStepHandler split).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/ls1hip.h"
+#include "grid.hpp"
+#include "molpair.hpp"
+
+namespace ls1 {
+
+struct MolSoA {  // one set of state arrays (two sets exist: the rebin gathers from one into the other)
+	double *x, *y, *z, *vx, *vy, *vz;
+	double *q0, *q1, *q2, *q3, *Dx, *Dy, *Dz;  // only allocated when the component set rotates
+	uint64_t* id;
+	int32_t* cid;
+};
+
+struct ForceSoA {
+	double *Fx, *Fy, *Fz, *Mx, *My, *Mz, *Vix, *Viy, *Viz;
+};
+
+struct HaloStage {  // unsorted halo copies (local images + imported records)
+	double *x, *y, *z, *q0, *q1, *q2, *q3;
+	uint64_t* id;
+	int32_t* cid;
+	uint32_t *key, *rank;
+};
+
+// device-side counters / flags, one small struct in device memory (no host sync needed inside the step)
+struct DevCounters {
+	uint32_t n_real;       // owned molecules after the last rebin
+	uint32_t n_halo;       // halo copies sorted into the halo segment
+	uint32_t n_halo_staged;// halo copies staged (local images + imported), before sorting
+	uint32_t n_stay;       // scratch: owned molecules that stay on this rank
+	uint32_t exp_leave[27];
+	uint32_t exp_halo[27];
+	uint32_t err_lost;     // molecules that left the halo region
+	uint32_t err_overflow; // capacity overflows
+	unsigned long long dist_checks, pairs_in_range;
+	double macro[4];       // u6, uX, rf, virial of the current traversal
+	double kin[2];         // sum m v^2, sum I w^2
+	unsigned long long kin_n, kin_rotdof;
+};
+
+struct ForceParams {
+	Grid g;
+	const double *x, *y, *z, *q0, *q1, *q2, *q3;
+	const int32_t* cid;
+	const uint32_t *cell_begin, *cell_end, *ckey;
+	double *Fx, *Fy, *Fz, *Mx, *My, *Mz, *Vix, *Viy, *Viz;
+	const CompTable* ct;
+	DevCounters* cnt;
+	double* partials;  // [gridDim][4]
+	uint32_t n_real_cap;  // launch bound (n_real is read from cnt for device-driven loops)
+	int which;         // 0 all, 1 inner cells, 2 boundary cells, 3 all non-halo cells (seam A)
+	uint32_t n_fixed;  // if != 0: number of molecules (overrides cnt->n_real; seam A)
+	int count_pairs;
+	// 1CLJ fast-path scalars
+	double eps24, sig2, shift6, rc2;
+};
+
+struct Timer {
+	std::vector<hipEvent_t> ev;  // start/stop pairs
+	size_t used = 0;
+	double total_ms = 0;
+	uint64_t launches = 0;
+};
+
+}  // namespace ls1
+
+struct ls1hip_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	std::string err;
+	// options
+	long opt_force_kernel = LS1HIP_FK_AUTO, opt_cic = 1, opt_vi = 0, opt_det = 1, opt_count_pairs = 0;
+	// model
+	bool have_comp = false, have_domain = false;
+	ls1::CompTable h_ct;
+	ls1::CompTable* d_ct = nullptr;
+	double rc = 0, rc_lj = 0;
+	bool one_clj = false;
+	// domain
+	ls1::Grid g;
+	double global_len[3] = {0, 0, 0};
+	int my_rank = 0;
+	int nbr[27];
+	double shift[27][3];  // position shift applied to a copy/leaver sent in direction d
+	bool has_remote = false;
+	// molecules
+	size_t cap_real = 0, cap_halo = 0;
+	size_t n_real = 0;  // host view (valid when !dirty_counts)
+	size_t n_halo = 0;
+	uint32_t pending_in = 0;  // molecules in the source set during a split rebin (owned + imported)
+	ls1::MolSoA mol[2];
+	int cur = 0;
+	ls1::ForceSoA frc;
+	ls1::HaloStage hs;
+	uint32_t *d_key = nullptr, *d_rank = nullptr, *d_perm = nullptr, *d_ckey = nullptr;
+	uint32_t *d_count = nullptr, *d_cell_begin = nullptr, *d_cell_end = nullptr, *d_blocksum = nullptr;
+	size_t cells_alloc = 0;
+	ls1::DevCounters* d_cnt = nullptr;
+	ls1::DevCounters* h_cnt = nullptr;  // pinned mirror
+	double* d_partials = nullptr;
+	size_t partials_cap = 0;
+	double* d_exp_leave = nullptr;  // per-direction slices, LS1HIP_LEAVING_DOUBLES per record
+	double* d_exp_halo = nullptr;   // per-direction slices, LS1HIP_HALO_DOUBLES per record
+	uint32_t exp_off_leave[28], exp_off_halo[28];
+	bool forces_valid = false, halo_valid = false, binned = false;
+	// timing
+	bool timing_on = false;
+	ls1::Timer t_force, t_integrate, t_rebin, t_halo;
+	std::vector<void*> allocs;
+};
+
+namespace ls1 {
+
+// ---- kernel launchers (definitions in kernels_*.hip) --------------------------------------------------------------
+struct RebinArgs {
+	Grid g;
+	MolSoA src, dst;
+	bool has_rot;
+	uint32_t *key, *rank, *perm, *ckey, *count, *cell_begin, *cell_end, *blocksum;
+	DevCounters* cnt;
+	uint32_t n_in;      // molecules in src (launch bound)
+	int nbr[27];
+	int my_rank;
+	double shift[27][3];
+	double* exp_leave;
+	uint32_t exp_off[28];  // record offsets of each direction's slice in exp_leave (exp_off[27] = total)
+	uint32_t cap_real;
+	int deterministic;
+};
+void launch_rebin_classify(const RebinArgs& a, hipStream_t s);
+void launch_rebin_sort_gather(const RebinArgs& a, hipStream_t s);
+
+struct HaloArgs {
+	Grid g;
+	MolSoA mol;  // current set; halo segment is written at [n_real, ...)
+	HaloStage hs;
+	bool has_rot;
+	uint32_t *perm, *count, *cell_begin, *cell_end, *blocksum;
+	DevCounters* cnt;
+	uint32_t n_real_cap, cap_halo;
+	int nbr[27];
+	int my_rank;
+	double shift[27][3];
+	double rc;
+	double* exp_halo;
+	uint32_t exp_off[28];
+	int deterministic;
+};
+void launch_halo_generate(const HaloArgs& a, hipStream_t s);
+void launch_halo_import(const HaloArgs& a, const double* dev_records, uint32_t n, hipStream_t s);
+void launch_halo_finalize(const HaloArgs& a, hipStream_t s);
+void launch_leave_import(const RebinArgs& a, const double* dev_records, uint32_t n, uint32_t at, hipStream_t s);
+void launch_pack_copy(double* dst, const double* src, uint32_t ndoubles, hipStream_t s);
+
+void launch_force_generic(const ForceParams& p, bool one_clj, bool with_vi, bool has_rot, hipStream_t s, uint32_t* nblocks);
+// LDS-tiled 1CLJ kernel (kernels_force_lj.hip); returns false if it cannot handle the configuration
+bool launch_force_lj(const ForceParams& p, hipStream_t s, uint32_t* nblocks, double* partials, size_t partials_cap);
+void launch_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, hipStream_t s);
+void launch_clear_macro(DevCounters* cnt, hipStream_t s);
+
+struct IntegArgs {
+	MolSoA mol;
+	ForceSoA frc;
+	const CompTable* ct;
+	DevCounters* cnt;
+	double* partials;
+	uint32_t n_cap;
+	bool has_rot;
+	double dt;
+};
+void launch_kick_drift(const IntegArgs& a, hipStream_t s);
+void launch_kick(const IntegArgs& a, hipStream_t s, uint32_t* nblocks);
+void launch_kin_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, hipStream_t s);
+
+}  // namespace ls1

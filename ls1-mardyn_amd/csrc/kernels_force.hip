@@ -1,0 +1,208 @@
+// kernels_force.hip — the generic pair-force kernel (any component set, any density).
+//
+// One lane per owned molecule i ("full shell": the lane accumulates everything its molecule receives, so there
+// are no force atomics and no cross-lane reductions in the hot loop; the result is deterministic).  The lane walks
+// the (2*hw+1)^3 cell neighbourhood of its cell through cell_begin/cell_end and reads neighbour data straight from
+// the cell-sorted SoA in HBM/L2.  This is the always-correct path: the faster LDS-tiled 1CLJ kernel
+// (kernels_force_lj.hip) falls back to it for pathological densities, and the multi-site / electrostatic
+// component sets use it directly.
+//
+// Reference semantics restated (see also molpair.hpp):
+//   pair set + halo policy   C08BasedTraversals::processBaseCell (LinkedCellTraversals/C08BasedTraversals.h:48-99),
+//                            VectorizedCellProcessor::processCell/processCellPair (VectorizedCellProcessor.cpp:2734-2821)
+//   masks                    strict r^2 < rc^2 on molecule centres, r^2 != 0 (SIMD_VectorizedCellProcessorHelpers.h:344-422)
+//   macroscopic sums         every unordered pair once: here each ordered pair (i owned, j owned or halo copy)
+//                            contributes 1/2, which sums to exactly the reference's "halo cell with larger index"
+//                            rule because a pair crossing a periodic/rank boundary is seen once from either side.
+//   endTraversal             upot = u6/6 + uX + rf, virial = vir + 3 rf (VectorizedCellProcessor.cpp:155-156)
+#include "common.hpp"
+
+namespace ls1 {
+
+constexpr int FTPB = 128;
+
+__device__ __forceinline__ double wave_sum(double v) {
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+	return v;
+}
+
+// block reduction of 4 doubles -> partials[blockIdx.x][4]
+__device__ __forceinline__ void block_reduce4(double v0, double v1, double v2, double v3, double* partials, int nwaves) {
+	__shared__ double red[16][4];
+	v0 = wave_sum(v0);
+	v1 = wave_sum(v1);
+	v2 = wave_sum(v2);
+	v3 = wave_sum(v3);
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	if (lane == 0) {
+		red[w][0] = v0;
+		red[w][1] = v1;
+		red[w][2] = v2;
+		red[w][3] = v3;
+	}
+	__syncthreads();
+	if (threadIdx.x < 4) {
+		double s = 0.;
+		for (int i = 0; i < nwaves; ++i) s += red[i][threadIdx.x];
+		partials[(size_t)blockIdx.x * 4 + threadIdx.x] = s;
+	}
+}
+
+__device__ __forceinline__ bool cell_is_innermost(const Grid& g, int cx, int cy, int cz) {
+	// no halo cell in the (2hw+1)^3 neighbourhood: LinkedCells "innermost" cells (CellBorderAndFlagManager.h:96-130)
+	const int lo = 2 * g.hw;
+	return cx >= lo && cy >= lo && cz >= lo && cx < g.dims[0] - lo && cy < g.dims[1] - lo && cz < g.dims[2] - lo;
+}
+
+template <bool ONE_CLJ, bool WITH_VI, bool HAS_ROT>
+__global__ void __launch_bounds__(FTPB) k_force_generic(ForceParams P) {
+	const uint32_t p = blockIdx.x * FTPB + threadIdx.x;
+	const uint32_t n_real = P.n_fixed ? P.n_fixed : P.cnt->n_real;
+	bool active = p < n_real;
+	int cx = 0, cy = 0, cz = 0;
+	if (active) {
+		cell_coords(P.g, (int)P.ckey[p], cx, cy, cz);
+		if (P.which == 3) {
+			active = !cell_is_halo(P.g, cx, cy, cz);
+		} else if (P.which != 0) {
+			const bool inner = cell_is_innermost(P.g, cx, cy, cz);
+			active = (P.which == 1) ? inner : !inner;
+		}
+	}
+	MolAcc acc;
+	acc.F = {0., 0., 0.};
+	acc.M = {0., 0., 0.};
+	acc.Vi = {0., 0., 0.};
+	acc.u6 = acc.uX = acc.rf = acc.vir = 0.;
+	unsigned long long nchk = 0, nhit = 0;
+	if (active) {
+		const V3 ri = {P.x[p], P.y[p], P.z[p]};
+		int ci = 0;
+		Rot Ri;
+		if (!ONE_CLJ) {
+			ci = P.cid[p];
+			if (HAS_ROT) {
+				// FullMolecule::setupSoACache normalises q before rotating (FullMolecule.cpp:720)
+				double w = P.q0[p], x = P.q1[p], y = P.q2[p], z = P.q3[p];
+				const double inv = 1. / sqrt(w * w + x * x + y * y + z * z);
+				Ri = rot_of(w * inv, x * inv, y * inv, z * inv);
+			} else {
+				Ri = rot_of(1., 0., 0., 0.);
+			}
+		}
+		const double rc2 = ONE_CLJ ? P.rc2 : P.ct->rc2;
+		const double rclj2 = ONE_CLJ ? P.rc2 : P.ct->rclj2;
+		const int hw = P.g.hw;
+		for (int dz = -hw; dz <= hw; ++dz)
+			for (int dy = -hw; dy <= hw; ++dy)
+				for (int dx = -hw; dx <= hw; ++dx) {
+					const int c2 = cell_index(P.g, cx + dx, cy + dy, cz + dz);
+					const uint32_t jb = P.cell_begin[c2], je = P.cell_end[c2];
+					for (uint32_t j = jb; j < je; ++j) {
+						if (j == p) continue;
+						const V3 rj = {P.x[j], P.y[j], P.z[j]};
+						const V3 drm = ri - rj;
+						const double dd = dot(drm, drm);
+						++nchk;
+						if (!(dd < rc2) || dd == 0.) continue;
+						++nhit;
+						if (ONE_CLJ) {
+							if (dd < rclj2) {
+								V3 f;
+								double u;
+								lj(drm, dd, P.eps24, P.sig2, f, u);
+								acc.F = acc.F + f;
+								acc.u6 += 0.5 * (u + P.shift6);
+								acc.vir += 0.5 * dot(drm, f);
+								if (WITH_VI) {
+									acc.Vi.x += 0.5 * drm.x * f.x;
+									acc.Vi.y += 0.5 * drm.y * f.y;
+									acc.Vi.z += 0.5 * drm.z * f.z;
+								}
+							}
+						} else {
+							const int cj = P.cid[j];
+							Rot Rj;
+							if (HAS_ROT) {
+								double w = P.q0[j], x = P.q1[j], y = P.q2[j], z = P.q3[j];
+								const double inv = 1. / sqrt(w * w + x * x + y * y + z * z);
+								Rj = rot_of(w * inv, x * inv, y * inv, z * inv);
+							} else {
+								Rj = rot_of(1., 0., 0., 0.);
+							}
+							mol_pair<WITH_VI>(*P.ct, ci, ri, Ri, cj, rj, Rj, drm, dd < rclj2, 0.5, acc);
+						}
+					}
+				}
+		P.Fx[p] = acc.F.x;
+		P.Fy[p] = acc.F.y;
+		P.Fz[p] = acc.F.z;
+		if (HAS_ROT) {
+			P.Mx[p] = acc.M.x;
+			P.My[p] = acc.M.y;
+			P.Mz[p] = acc.M.z;
+		}
+		if (WITH_VI) {
+			P.Vix[p] = acc.Vi.x;
+			P.Viy[p] = acc.Vi.y;
+			P.Viz[p] = acc.Vi.z;
+		}
+	}
+	block_reduce4(acc.u6, acc.uX, acc.rf, acc.vir, P.partials, FTPB / 64);
+	if (P.count_pairs) {
+		// wave-aggregated by the compiler; diagnostics only
+		atomicAdd(&P.cnt->dist_checks, nchk);
+		atomicAdd(&P.cnt->pairs_in_range, nhit);
+	}
+}
+
+template <bool A, bool B, bool C>
+static void launch_g(const ForceParams& p, dim3 grid, hipStream_t s) {
+	hipLaunchKernelGGL((k_force_generic<A, B, C>), grid, dim3(FTPB), 0, s, p);
+}
+
+void launch_force_generic(const ForceParams& p, bool one_clj, bool with_vi, bool has_rot, hipStream_t s,
+						  uint32_t* nblocks) {
+	const uint32_t nb = (p.n_real_cap + FTPB - 1) / FTPB;
+	*nblocks = nb;
+	if (nb == 0) return;
+	const dim3 grid(nb);
+	if (one_clj) {
+		if (with_vi) launch_g<true, true, false>(p, grid, s);
+		else launch_g<true, false, false>(p, grid, s);
+	} else if (has_rot) {
+		if (with_vi) launch_g<false, true, true>(p, grid, s);
+		else launch_g<false, false, true>(p, grid, s);
+	} else {
+		if (with_vi) launch_g<false, true, false>(p, grid, s);
+		else launch_g<false, false, false>(p, grid, s);
+	}
+}
+
+// deterministic second pass: one block sums the per-block partials in fixed order and ADDS them to cnt->macro
+__global__ void __launch_bounds__(256) k_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks) {
+	double v[4] = {0., 0., 0., 0.};
+	for (uint32_t b = threadIdx.x; b < nblocks; b += 256)
+		for (int k = 0; k < 4; ++k) v[k] += partials[(size_t)b * 4 + k];
+	__shared__ double red[4][4];
+	for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	if (lane == 0)
+		for (int k = 0; k < 4; ++k) red[w][k] = v[k];
+	__syncthreads();
+	if (threadIdx.x < 4) cnt->macro[threadIdx.x] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+void launch_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, hipStream_t s) {
+	if (nblocks == 0) return;
+	hipLaunchKernelGGL(k_force_reduce, dim3(1), dim3(256), 0, s, cnt, partials, nblocks);
+}
+
+__global__ void k_clear_macro(DevCounters* cnt) {
+	for (int k = 0; k < 4; ++k) cnt->macro[k] = 0.;
+	cnt->dist_checks = 0;
+	cnt->pairs_in_range = 0;
+}
+void launch_clear_macro(DevCounters* cnt, hipStream_t s) { hipLaunchKernelGGL(k_clear_macro, dim3(1), dim3(1), 0, s, cnt); }
+
+}  // namespace ls1

@@ -1,0 +1,154 @@
+// kernels_integrate.hip — Leapfrog integrator as two streaming kernels over the device-resident SoA (HBM-bound:
+// pre-force pass reads r,v,F and writes r,v = 120 B per molecule; post-force pass reads v,F, writes v = 72 B).
+//
+// Restates FullMolecule::upd_preF (/root/reference/src/molecules/FullMolecule.cpp:334-364) and upd_postF (:366-389)
+// as driven by Leapfrog::transition1to2 / transition2to3 (/root/reference/src/integrators/Leapfrog.cpp:48-64,66-150).
+#include "common.hpp"
+
+namespace ls1 {
+
+constexpr int ITPB = 256;
+
+__device__ __forceinline__ void q_diff(const double q[4], V3 w, double dq[4]) {
+	// Quaternion::differentiate, molecules/Quaternion.cpp:93-98
+	dq[0] = .5 * (-q[1] * w.x - q[2] * w.y - q[3] * w.z);
+	dq[1] = .5 * (q[0] * w.x - q[3] * w.y + q[2] * w.z);
+	dq[2] = .5 * (q[3] * w.x + q[0] * w.y - q[1] * w.z);
+	dq[3] = .5 * (-q[2] * w.x + q[1] * w.y + q[0] * w.z);
+}
+
+template <bool HAS_ROT>
+__global__ void __launch_bounds__(ITPB) k_kick_drift(IntegArgs a) {
+	const uint32_t p = blockIdx.x * ITPB + threadIdx.x;
+	if (p >= a.cnt->n_real) return;
+	const double dt = a.dt, dt_halve = .5 * dt;
+	const int c = HAS_ROT ? a.mol.cid[p] : (a.ct->ncomp > 1 ? a.mol.cid[p] : 0);
+	const double dtInv2m = dt_halve / a.ct->mass[c];
+	double vx = a.mol.vx[p] + dtInv2m * a.frc.Fx[p];
+	double vy = a.mol.vy[p] + dtInv2m * a.frc.Fy[p];
+	double vz = a.mol.vz[p] + dtInv2m * a.frc.Fz[p];
+	a.mol.vx[p] = vx;
+	a.mol.vy[p] = vy;
+	a.mol.vz[p] = vz;
+	a.mol.x[p] += dt * vx;
+	a.mol.y[p] += dt * vy;
+	a.mol.z[p] += dt * vz;
+	if (HAS_ROT) {
+		double q[4] = {a.mol.q0[p], a.mol.q1[p], a.mol.q2[p], a.mol.q3[p]};
+		V3 D = {a.mol.Dx[p], a.mol.Dy[p], a.mol.Dz[p]};
+		const V3 invI = {a.ct->invI[c][0], a.ct->invI[c][1], a.ct->invI[c][2]};
+		V3 w = rotate_inv(rot_of(q[0], q[1], q[2], q[3]), D);
+		w = {w.x * invI.x, w.y * invI.y, w.z * invI.z};
+		double dq[4], qh[4];
+		q_diff(q, w, dq);
+		for (int k = 0; k < 4; ++k) qh[k] = dq[k] * dt_halve + q[k];
+		double qcorr = 1. / sqrt(qh[0] * qh[0] + qh[1] * qh[1] + qh[2] * qh[2] + qh[3] * qh[3]);
+		for (int k = 0; k < 4; ++k) qh[k] *= qcorr;
+		D.x += dt_halve * a.frc.Mx[p];
+		D.y += dt_halve * a.frc.My[p];
+		D.z += dt_halve * a.frc.Mz[p];
+		w = rotate_inv(rot_of(qh[0], qh[1], qh[2], qh[3]), D);
+		w = {w.x * invI.x, w.y * invI.y, w.z * invI.z};
+		q_diff(qh, w, dq);
+		for (int k = 0; k < 4; ++k) q[k] += dq[k] * dt;
+		qcorr = 1. / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+		a.mol.q0[p] = q[0] * qcorr;
+		a.mol.q1[p] = q[1] * qcorr;
+		a.mol.q2[p] = q[2] * qcorr;
+		a.mol.q3[p] = q[3] * qcorr;
+		a.mol.Dx[p] = D.x;
+		a.mol.Dy[p] = D.y;
+		a.mol.Dz[p] = D.z;
+	}
+}
+
+__device__ __forceinline__ double wave_sum_i(double v) {
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+	return v;
+}
+
+template <bool HAS_ROT>
+__global__ void __launch_bounds__(ITPB) k_kick(IntegArgs a) {
+	const uint32_t p = blockIdx.x * ITPB + threadIdx.x;
+	double mv2 = 0., Iw2 = 0., rdof = 0.;
+	if (p < a.cnt->n_real) {
+		const double dt_halve = a.dt;
+		const int c = HAS_ROT ? a.mol.cid[p] : (a.ct->ncomp > 1 ? a.mol.cid[p] : 0);
+		const double m = a.ct->mass[c];
+		const double dtInv2m = dt_halve / m;
+		const double vx = a.mol.vx[p] + dtInv2m * a.frc.Fx[p];
+		const double vy = a.mol.vy[p] + dtInv2m * a.frc.Fy[p];
+		const double vz = a.mol.vz[p] + dtInv2m * a.frc.Fz[p];
+		a.mol.vx[p] = vx;
+		a.mol.vy[p] = vy;
+		a.mol.vz[p] = vz;
+		mv2 = m * (vx * vx + vy * vy + vz * vz);
+		rdof = (double)a.ct->rotdof[c];
+		if (HAS_ROT) {
+			V3 D = {a.mol.Dx[p] + dt_halve * a.frc.Mx[p], a.mol.Dy[p] + dt_halve * a.frc.My[p],
+					a.mol.Dz[p] + dt_halve * a.frc.Mz[p]};
+			a.mol.Dx[p] = D.x;
+			a.mol.Dy[p] = D.y;
+			a.mol.Dz[p] = D.z;
+			V3 w = rotate_inv(rot_of(a.mol.q0[p], a.mol.q1[p], a.mol.q2[p], a.mol.q3[p]), D);
+			w = {w.x * a.ct->invI[c][0], w.y * a.ct->invI[c][1], w.z * a.ct->invI[c][2]};
+			Iw2 = a.ct->I[c][0] * w.x * w.x + a.ct->I[c][1] * w.y * w.y + a.ct->I[c][2] * w.z * w.z;
+		}
+	}
+	__shared__ double red[ITPB / 64][3];
+	mv2 = wave_sum_i(mv2);
+	Iw2 = wave_sum_i(Iw2);
+	rdof = wave_sum_i(rdof);
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	if (lane == 0) {
+		red[w][0] = mv2;
+		red[w][1] = Iw2;
+		red[w][2] = rdof;
+	}
+	__syncthreads();
+	if (threadIdx.x < 3) {
+		double s = 0.;
+		for (int i = 0; i < ITPB / 64; ++i) s += red[i][threadIdx.x];
+		a.partials[(size_t)blockIdx.x * 4 + threadIdx.x] = s;
+	}
+}
+
+void launch_kick_drift(const IntegArgs& a, hipStream_t s) {
+	if (a.n_cap == 0) return;
+	const dim3 grid((a.n_cap + ITPB - 1) / ITPB);
+	if (a.has_rot) hipLaunchKernelGGL(k_kick_drift<true>, grid, dim3(ITPB), 0, s, a);
+	else hipLaunchKernelGGL(k_kick_drift<false>, grid, dim3(ITPB), 0, s, a);
+}
+
+void launch_kick(const IntegArgs& a, hipStream_t s, uint32_t* nblocks) {
+	const uint32_t nb = (a.n_cap + ITPB - 1) / ITPB;
+	*nblocks = nb;
+	if (nb == 0) return;
+	if (a.has_rot) hipLaunchKernelGGL(k_kick<true>, dim3(nb), dim3(ITPB), 0, s, a);
+	else hipLaunchKernelGGL(k_kick<false>, dim3(nb), dim3(ITPB), 0, s, a);
+}
+
+__global__ void __launch_bounds__(256) k_kin_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks) {
+	double v[3] = {0., 0., 0.};
+	for (uint32_t b = threadIdx.x; b < nblocks; b += 256)
+		for (int k = 0; k < 3; ++k) v[k] += partials[(size_t)b * 4 + k];
+	__shared__ double red[4][3];
+	for (int k = 0; k < 3; ++k) v[k] = wave_sum_i(v[k]);
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	if (lane == 0)
+		for (int k = 0; k < 3; ++k) red[w][k] = v[k];
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		cnt->kin[0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+		cnt->kin[1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+		cnt->kin_n = cnt->n_real;
+		cnt->kin_rotdof = (unsigned long long)(red[0][2] + red[1][2] + red[2][2] + red[3][2] + 0.5);
+	}
+}
+
+void launch_kin_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, hipStream_t s) {
+	if (nblocks == 0) return;
+	hipLaunchKernelGGL(k_kin_reduce, dim3(1), dim3(256), 0, s, cnt, partials, nblocks);
+}
+
+}  // namespace ls1

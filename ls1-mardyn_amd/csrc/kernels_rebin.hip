@@ -1,0 +1,505 @@
+// kernels_rebin.hip — device re-binning (counting sort by cell), periodic wrap / leaver packing and halo-copy
+// generation.  All streaming, HBM-bound integer/byte work: coalesced SoA reads, one atomic per molecule on a
+// per-cell counter (u32, ~12 hits per counter), canonical in-cell order by molecule id so that results do not
+// depend on atomic arrival order.
+//
+// Reference behaviour restated here:
+//   LinkedCells::update / update_via_copies        particleContainer/LinkedCells.cpp:243-356
+//   handleDomainLeavingParticles                   parallel/DomainDecompBase.cpp:174-225
+//   populateHaloLayerWithCopies                    parallel/DomainDecompBase.cpp:293-348
+//   CommunicationBuffer record fields              parallel/CommunicationBuffer.cpp:131-145,167-176
+#include "common.hpp"
+
+namespace ls1 {
+
+constexpr uint32_t KEY_INVALID = 0xffffffffu;
+constexpr int TPB = 256;
+
+__device__ __forceinline__ double next_toward_up(double x) { return nextafter(x, x + 1.0); }
+__device__ __forceinline__ double next_toward_down(double x) { return nextafter(x, x - 1.0); }
+
+// ---- stage A: wrap / classify / key / in-cell rank --------------------------------------------------------------
+__global__ void __launch_bounds__(TPB) k_classify(RebinArgs a) {
+	const uint32_t p = blockIdx.x * TPB + threadIdx.x;
+	if (p >= a.n_in) return;
+	double r[3] = {a.src.x[p], a.src.y[p], a.src.z[p]};
+	int s[3];
+	bool out = false;
+	for (int d = 0; d < 3; ++d) {
+		s[d] = (r[d] < a.g.bmin[d]) ? -1 : ((r[d] >= a.g.bmax[d]) ? 1 : 0);
+		out |= (s[d] != 0);
+	}
+	uint32_t key = KEY_INVALID;
+	if (out) {
+		const int dir = (s[2] + 1) * 9 + (s[1] + 1) * 3 + (s[0] + 1);
+		const int dest = a.nbr[dir];
+		if (dest == a.my_rank) {
+			// periodic wrap handled on this rank, incl. the reference's rounding clamps (DomainDecompBase.cpp:206-219)
+			for (int d = 0; d < 3; ++d) {
+				const double sh = a.shift[dir][d];
+				if (sh == 0.) continue;
+				r[d] += sh;
+				if (sh < 0.) {
+					if (r[d] <= a.g.bmin[d]) r[d] = a.g.bmin[d];
+				} else {
+					if (r[d] >= a.g.bmax[d]) r[d] = next_toward_down(a.g.bmax[d]);
+				}
+			}
+			a.src.x[p] = r[0];
+			a.src.y[p] = r[1];
+			a.src.z[p] = r[2];
+			out = false;
+			for (int d = 0; d < 3; ++d) out |= (r[d] < a.g.bmin[d]) || (r[d] >= a.g.bmax[d]);
+			if (out) {
+				atomicAdd(&a.cnt->err_lost, 1u);  // moved by more than a box length
+				a.key[p] = KEY_INVALID;
+				return;
+			}
+		} else if (dest < 0) {
+			atomicAdd(&a.cnt->err_lost, 1u);  // left through an open boundary
+			a.key[p] = KEY_INVALID;
+			return;
+		} else {
+			// leaves towards another rank: pack the reference's "leaving molecule" record, receiver frame
+			const uint32_t slot = atomicAdd(&a.cnt->exp_leave[dir], 1u);
+			const uint32_t cap = a.exp_off[dir + 1] - a.exp_off[dir];
+			if (slot >= cap) {
+				atomicAdd(&a.cnt->err_overflow, 1u);
+			} else {
+				double* rec = a.exp_leave + (size_t)(a.exp_off[dir] + slot) * LS1HIP_LEAVING_DOUBLES;
+				rec[0] = __longlong_as_double((long long)a.src.id[p]);
+				rec[1] = __longlong_as_double((long long)a.src.cid[p]);
+				rec[2] = r[0] + a.shift[dir][0];
+				rec[3] = r[1] + a.shift[dir][1];
+				rec[4] = r[2] + a.shift[dir][2];
+				rec[5] = a.src.vx[p];
+				rec[6] = a.src.vy[p];
+				rec[7] = a.src.vz[p];
+				if (a.has_rot) {
+					rec[8] = a.src.q0[p];
+					rec[9] = a.src.q1[p];
+					rec[10] = a.src.q2[p];
+					rec[11] = a.src.q3[p];
+					rec[12] = a.src.Dx[p];
+					rec[13] = a.src.Dy[p];
+					rec[14] = a.src.Dz[p];
+				} else {
+					rec[8] = 1.;
+					rec[9] = rec[10] = rec[11] = rec[12] = rec[13] = rec[14] = 0.;
+				}
+			}
+			a.key[p] = KEY_INVALID;
+			return;
+		}
+	}
+	const int cx = cell_coord_owned(a.g, 0, r[0]);
+	const int cy = cell_coord_owned(a.g, 1, r[1]);
+	const int cz = cell_coord_owned(a.g, 2, r[2]);
+	key = (uint32_t)cell_index(a.g, cx, cy, cz);
+	a.key[p] = key;
+	a.rank[p] = atomicAdd(&a.count[key], 1u);
+}
+
+// ---- exclusive scan over the cell grid, restricted to one cell class --------------------------------------------
+// mode 0: inner/boundary cells (halo cells contribute 0), result base 0,      total -> cnt->n_real
+// mode 1: halo cells,                                     result base n_real, total -> cnt->n_halo
+constexpr int SCAN_ITEMS = 4;
+constexpr int SCAN_BLOCK = TPB * SCAN_ITEMS;
+
+__device__ __forceinline__ uint32_t scan_val(const Grid& g, const uint32_t* count, int c, int mode) {
+	if (c >= g.ncells) return 0;
+	int cx, cy, cz;
+	cell_coords(g, c, cx, cy, cz);
+	const bool h = cell_is_halo(g, cx, cy, cz);
+	return (h == (mode == 1)) ? count[c] : 0u;
+}
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total) {
+	__shared__ uint32_t wsum[TPB / 64];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	uint32_t inc = v;
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t t = __shfl_up(inc, o);
+		if (lane >= o) inc += t;
+	}
+	if (lane == 63) wsum[w] = inc;
+	__syncthreads();
+	uint32_t base = 0, tot = 0;
+	for (int i = 0; i < TPB / 64; ++i) {
+		if (i < w) base += wsum[i];
+		tot += wsum[i];
+	}
+	__syncthreads();
+	*total = tot;
+	return base + inc - v;
+}
+
+__global__ void __launch_bounds__(TPB) k_scan_blocksums(Grid g, const uint32_t* count, uint32_t* blocksum, int mode) {
+	const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
+	uint32_t v = 0;
+	for (int i = 0; i < SCAN_ITEMS; ++i) v += scan_val(g, count, base + i, mode);
+	uint32_t tot;
+	block_exclusive_scan(v, &tot);
+	if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(TPB) k_scan_top(uint32_t* blocksum, int nblocks, DevCounters* cnt, int mode) {
+	// single block: exclusive scan of the block sums in chunks of TPB
+	__shared__ uint32_t carry;
+	if (threadIdx.x == 0) carry = (mode == 1) ? cnt->n_real : 0u;
+	__syncthreads();
+	for (int base = 0; base < nblocks; base += TPB) {
+		const int i = base + threadIdx.x;
+		const uint32_t v = (i < nblocks) ? blocksum[i] : 0u;
+		uint32_t tot;
+		const uint32_t ex = block_exclusive_scan(v, &tot);
+		const uint32_t c = carry;
+		if (i < nblocks) blocksum[i] = c + ex;
+		__syncthreads();
+		if (threadIdx.x == 0) carry = c + tot;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		if (mode == 0) cnt->n_real = carry;
+		else cnt->n_halo = carry - cnt->n_real;
+	}
+}
+
+__global__ void __launch_bounds__(TPB) k_scan_apply(Grid g, const uint32_t* count, const uint32_t* blocksum,
+													uint32_t* cell_begin, uint32_t* cell_end, int mode) {
+	const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
+	uint32_t vals[SCAN_ITEMS], v = 0;
+	for (int i = 0; i < SCAN_ITEMS; ++i) {
+		vals[i] = scan_val(g, count, base + i, mode);
+		v += vals[i];
+	}
+	uint32_t tot;
+	uint32_t ex = block_exclusive_scan(v, &tot) + blocksum[blockIdx.x];
+	for (int i = 0; i < SCAN_ITEMS; ++i) {
+		const int c = base + i;
+		if (c < g.ncells) {
+			int cx, cy, cz;
+			cell_coords(g, c, cx, cy, cz);
+			if (cell_is_halo(g, cx, cy, cz) == (mode == 1)) {
+				cell_begin[c] = ex;
+				cell_end[c] = ex + vals[i];
+			}
+		}
+		ex += vals[i];
+	}
+}
+
+static void run_scan(const Grid& g, const uint32_t* count, uint32_t* blocksum, uint32_t* cell_begin, uint32_t* cell_end,
+					 DevCounters* cnt, int mode, hipStream_t s) {
+	const int nblocks = (g.ncells + SCAN_BLOCK - 1) / SCAN_BLOCK;
+	hipLaunchKernelGGL(k_scan_blocksums, dim3(nblocks), dim3(TPB), 0, s, g, count, blocksum, mode);
+	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(TPB), 0, s, blocksum, nblocks, cnt, mode);
+	hipLaunchKernelGGL(k_scan_apply, dim3(nblocks), dim3(TPB), 0, s, g, count, blocksum, cell_begin, cell_end, mode);
+}
+
+// ---- stage B: scatter -> canonical in-cell order -> gather ------------------------------------------------------
+__global__ void __launch_bounds__(TPB) k_scatter(const uint32_t* key, const uint32_t* rank, const uint32_t* cell_begin,
+												 uint32_t* perm, uint32_t n, uint32_t sub) {
+	const uint32_t p = blockIdx.x * TPB + threadIdx.x;
+	if (p >= n) return;
+	const uint32_t k = key[p];
+	if (k == KEY_INVALID) return;
+	perm[cell_begin[k] + rank[p] - sub] = p;
+}
+
+// one thread per cell: insertion sort of the cell's slice of `perm` by molecule id (cells hold ~12 molecules)
+__global__ void __launch_bounds__(TPB) k_cellsort(Grid g, const uint32_t* cell_begin, const uint32_t* cell_end,
+												  uint32_t* perm, const uint64_t* id, const DevCounters* cnt, int mode) {
+	const int c = blockIdx.x * TPB + threadIdx.x;
+	if (c >= g.ncells) return;
+	int cx, cy, cz;
+	cell_coords(g, c, cx, cy, cz);
+	if (cell_is_halo(g, cx, cy, cz) != (mode == 1)) return;
+	const uint32_t sub = (mode == 1) ? cnt->n_real : 0u;
+	const uint32_t b = cell_begin[c] - sub, e = cell_end[c] - sub;
+	for (uint32_t i = b + 1; i < e; ++i) {
+		const uint32_t pi = perm[i];
+		const uint64_t idi = id[pi];
+		uint32_t j = i;
+		while (j > b) {
+			const uint32_t pj = perm[j - 1];
+			if (id[pj] <= idi) break;
+			perm[j] = pj;
+			--j;
+		}
+		perm[j] = pi;
+	}
+}
+
+__global__ void __launch_bounds__(TPB) k_gather(RebinArgs a) {
+	const uint32_t p = blockIdx.x * TPB + threadIdx.x;
+	if (p >= a.cnt->n_real) return;
+	const uint32_t i = a.perm[p];
+	a.dst.x[p] = a.src.x[i];
+	a.dst.y[p] = a.src.y[i];
+	a.dst.z[p] = a.src.z[i];
+	a.dst.vx[p] = a.src.vx[i];
+	a.dst.vy[p] = a.src.vy[i];
+	a.dst.vz[p] = a.src.vz[i];
+	a.dst.id[p] = a.src.id[i];
+	a.dst.cid[p] = a.src.cid[i];
+	a.ckey[p] = a.key[i];
+	if (a.has_rot) {
+		a.dst.q0[p] = a.src.q0[i];
+		a.dst.q1[p] = a.src.q1[i];
+		a.dst.q2[p] = a.src.q2[i];
+		a.dst.q3[p] = a.src.q3[i];
+		a.dst.Dx[p] = a.src.Dx[i];
+		a.dst.Dy[p] = a.src.Dy[i];
+		a.dst.Dz[p] = a.src.Dz[i];
+	}
+}
+
+void launch_rebin_classify(const RebinArgs& a, hipStream_t s) {
+	hipMemsetAsync(a.count, 0, sizeof(uint32_t) * (size_t)a.g.ncells, s);
+	hipMemsetAsync(&a.cnt->exp_leave[0], 0, sizeof(uint32_t) * 27, s);
+	if (a.n_in == 0) return;
+	hipLaunchKernelGGL(k_classify, dim3((a.n_in + TPB - 1) / TPB), dim3(TPB), 0, s, a);
+}
+
+void launch_rebin_sort_gather(const RebinArgs& a, hipStream_t s) {
+	run_scan(a.g, a.count, a.blocksum, a.cell_begin, a.cell_end, a.cnt, 0, s);
+	if (a.n_in == 0) return;
+	const dim3 grid((a.n_in + TPB - 1) / TPB);
+	hipLaunchKernelGGL(k_scatter, grid, dim3(TPB), 0, s, a.key, a.rank, a.cell_begin, a.perm, a.n_in, 0u);
+	if (a.deterministic)
+		hipLaunchKernelGGL(k_cellsort, dim3((a.g.ncells + TPB - 1) / TPB), dim3(TPB), 0, s, a.g, a.cell_begin, a.cell_end,
+						   a.perm, a.src.id, a.cnt, 0);
+	hipLaunchKernelGGL(k_gather, grid, dim3(TPB), 0, s, a);
+}
+
+// append received "leaving molecule" records to the source set at [at, at+n)
+__global__ void __launch_bounds__(TPB) k_leave_import(RebinArgs a, const double* rec, uint32_t n, uint32_t at) {
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= n) return;
+	const double* r = rec + (size_t)i * LS1HIP_LEAVING_DOUBLES;
+	const uint32_t p = at + i;
+	a.src.id[p] = (uint64_t)__double_as_longlong(r[0]);
+	a.src.cid[p] = (int32_t)__double_as_longlong(r[1]);
+	a.src.x[p] = r[2];
+	a.src.y[p] = r[3];
+	a.src.z[p] = r[4];
+	a.src.vx[p] = r[5];
+	a.src.vy[p] = r[6];
+	a.src.vz[p] = r[7];
+	if (a.has_rot) {
+		a.src.q0[p] = r[8];
+		a.src.q1[p] = r[9];
+		a.src.q2[p] = r[10];
+		a.src.q3[p] = r[11];
+		a.src.Dx[p] = r[12];
+		a.src.Dy[p] = r[13];
+		a.src.Dz[p] = r[14];
+	}
+	// bin on arrival (same rule as k_classify for a molecule inside the box)
+	const int cx = cell_coord_owned(a.g, 0, r[2]);
+	const int cy = cell_coord_owned(a.g, 1, r[3]);
+	const int cz = cell_coord_owned(a.g, 2, r[4]);
+	const uint32_t key = (uint32_t)cell_index(a.g, cx, cy, cz);
+	a.key[p] = key;
+	a.rank[p] = atomicAdd(&a.count[key], 1u);
+}
+
+void launch_leave_import(const RebinArgs& a, const double* dev_records, uint32_t n, uint32_t at, hipStream_t s) {
+	if (n == 0) return;
+	hipLaunchKernelGGL(k_leave_import, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, s, a, dev_records, n, at);
+}
+
+__global__ void __launch_bounds__(TPB) k_copy(double* dst, const double* src, uint32_t n) {
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i < n) dst[i] = src[i];
+}
+void launch_pack_copy(double* dst, const double* src, uint32_t ndoubles, hipStream_t s) {
+	if (ndoubles == 0) return;
+	hipLaunchKernelGGL(k_copy, dim3((ndoubles + TPB - 1) / TPB), dim3(TPB), 0, s, dst, src, ndoubles);
+}
+
+// ---- halo copies --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void halo_stage_write(const HaloArgs& a, uint32_t slot, const double r[3], uint64_t id,
+												  int32_t cid, double q0, double q1, double q2, double q3) {
+	a.hs.x[slot] = r[0];
+	a.hs.y[slot] = r[1];
+	a.hs.z[slot] = r[2];
+	a.hs.id[slot] = id;
+	a.hs.cid[slot] = cid;
+	if (a.has_rot) {
+		a.hs.q0[slot] = q0;
+		a.hs.q1[slot] = q1;
+		a.hs.q2[slot] = q2;
+		a.hs.q3[slot] = q3;
+	}
+	const int cx = cell_coord_any(a.g, 0, r[0]);
+	const int cy = cell_coord_any(a.g, 1, r[1]);
+	const int cz = cell_coord_any(a.g, 2, r[2]);
+	uint32_t key = KEY_INVALID;
+	if (cell_is_halo(a.g, cx, cy, cz)) {
+		key = (uint32_t)cell_index(a.g, cx, cy, cz);
+		a.hs.rank[slot] = atomicAdd(&a.count[key], 1u);
+	} else {
+		atomicAdd(&a.cnt->err_lost, 1u);  // a "halo copy" that lies inside the box
+	}
+	a.hs.key[slot] = key;
+}
+
+__global__ void __launch_bounds__(TPB) k_halo_gen(HaloArgs a) {
+	const uint32_t p = blockIdx.x * TPB + threadIdx.x;
+	if (p >= a.cnt->n_real) return;
+	const double r[3] = {a.mol.x[p], a.mol.y[p], a.mol.z[p]};
+	bool lo[3], hi[3];
+	bool any = false;
+	for (int d = 0; d < 3; ++d) {
+		lo[d] = r[d] < a.g.bmin[d] + a.rc;   // region [min, min+rc): DomainDecompBase.cpp:309-311
+		hi[d] = r[d] >= a.g.bmax[d] - a.rc;  // region [max-rc, max):  DomainDecompBase.cpp:312-315
+		any |= lo[d] | hi[d];
+	}
+	if (!any) return;
+	const uint64_t id = a.mol.id[p];
+	const int32_t cid = a.mol.cid[p];
+	double q0 = 1., q1 = 0., q2 = 0., q3 = 0.;
+	if (a.has_rot) {
+		q0 = a.mol.q0[p];
+		q1 = a.mol.q1[p];
+		q2 = a.mol.q2[p];
+		q3 = a.mol.q3[p];
+	}
+	for (int sz = -1; sz <= 1; ++sz) {
+		if (!(sz == 0 || (sz < 0 ? lo[2] : hi[2]))) continue;
+		for (int sy = -1; sy <= 1; ++sy) {
+			if (!(sy == 0 || (sy < 0 ? lo[1] : hi[1]))) continue;
+			for (int sx = -1; sx <= 1; ++sx) {
+				if (!(sx == 0 || (sx < 0 ? lo[0] : hi[0]))) continue;
+				if (sx == 0 && sy == 0 && sz == 0) continue;
+				const int dir = (sz + 1) * 9 + (sy + 1) * 3 + (sx + 1);
+				const int dest = a.nbr[dir];
+				if (dest < 0) continue;  // open boundary: no image from that side
+				double rn[3];
+				for (int d = 0; d < 3; ++d) rn[d] = r[d] + a.shift[dir][d];
+				if (dest == a.my_rank) {
+					// rounding guards of populateHaloLayerWithCopies (DomainDecompBase.cpp:330-343)
+					for (int d = 0; d < 3; ++d) {
+						const double sh = a.shift[dir][d];
+						if (sh < 0.) {
+							if (rn[d] >= a.g.bmin[d]) rn[d] = next_toward_down(a.g.bmin[d]);
+						} else if (sh > 0.) {
+							if (rn[d] < a.g.bmax[d]) rn[d] = next_toward_up(a.g.bmax[d]);
+						}
+					}
+					const uint32_t slot = atomicAdd(&a.cnt->n_halo_staged, 1u);
+					if (slot >= a.cap_halo) {
+						atomicAdd(&a.cnt->err_overflow, 1u);
+						continue;
+					}
+					halo_stage_write(a, slot, rn, id, cid, q0, q1, q2, q3);
+				} else {
+					const uint32_t slot = atomicAdd(&a.cnt->exp_halo[dir], 1u);
+					const uint32_t cap = a.exp_off[dir + 1] - a.exp_off[dir];
+					if (slot >= cap) {
+						atomicAdd(&a.cnt->err_overflow, 1u);
+						continue;
+					}
+					double* rec = a.exp_halo + (size_t)(a.exp_off[dir] + slot) * LS1HIP_HALO_DOUBLES;
+					rec[0] = __longlong_as_double((long long)id);
+					rec[1] = __longlong_as_double((long long)cid);
+					rec[2] = rn[0];
+					rec[3] = rn[1];
+					rec[4] = rn[2];
+					rec[5] = q0;
+					rec[6] = q1;
+					rec[7] = q2;
+					rec[8] = q3;
+				}
+			}
+		}
+	}
+}
+
+__global__ void __launch_bounds__(TPB) k_halo_import(HaloArgs a, const double* rec, uint32_t n) {
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= n) return;
+	const double* r = rec + (size_t)i * LS1HIP_HALO_DOUBLES;
+	const uint32_t slot = atomicAdd(&a.cnt->n_halo_staged, 1u);
+	if (slot >= a.cap_halo) {
+		atomicAdd(&a.cnt->err_overflow, 1u);
+		return;
+	}
+	const double rr[3] = {r[2], r[3], r[4]};
+	halo_stage_write(a, slot, rr, (uint64_t)__double_as_longlong(r[0]), (int32_t)__double_as_longlong(r[1]), r[5], r[6],
+					 r[7], r[8]);
+}
+
+__global__ void __launch_bounds__(TPB) k_halo_gather(HaloArgs a) {
+	const uint32_t k = blockIdx.x * TPB + threadIdx.x;
+	if (k >= a.cnt->n_halo) return;
+	const uint32_t i = a.perm[k];
+	const uint32_t p = a.cnt->n_real + k;
+	a.mol.x[p] = a.hs.x[i];
+	a.mol.y[p] = a.hs.y[i];
+	a.mol.z[p] = a.hs.z[i];
+	a.mol.id[p] = a.hs.id[i];
+	a.mol.cid[p] = a.hs.cid[i];
+	if (a.has_rot) {
+		a.mol.q0[p] = a.hs.q0[i];
+		a.mol.q1[p] = a.hs.q1[i];
+		a.mol.q2[p] = a.hs.q2[i];
+		a.mol.q3[p] = a.hs.q3[i];
+	}
+}
+
+__global__ void k_halo_reset(DevCounters* cnt) {
+	cnt->n_halo = 0;
+	cnt->n_halo_staged = 0;
+	for (int i = 0; i < 27; ++i) cnt->exp_halo[i] = 0;
+}
+
+// zero the per-cell counters of halo cells only (real cells keep their counts from the rebin)
+__global__ void __launch_bounds__(TPB) k_zero_halo_counts(Grid g, uint32_t* count) {
+	const int c = blockIdx.x * TPB + threadIdx.x;
+	if (c >= g.ncells) return;
+	int cx, cy, cz;
+	cell_coords(g, c, cx, cy, cz);
+	if (cell_is_halo(g, cx, cy, cz)) count[c] = 0;
+}
+
+void launch_halo_generate(const HaloArgs& a, hipStream_t s) {
+	hipLaunchKernelGGL(k_halo_reset, dim3(1), dim3(1), 0, s, a.cnt);
+	hipLaunchKernelGGL(k_zero_halo_counts, dim3((a.g.ncells + TPB - 1) / TPB), dim3(TPB), 0, s, a.g, a.count);
+	if (a.n_real_cap == 0) return;
+	hipLaunchKernelGGL(k_halo_gen, dim3((a.n_real_cap + TPB - 1) / TPB), dim3(TPB), 0, s, a);
+}
+
+void launch_halo_import(const HaloArgs& a, const double* dev_records, uint32_t n, hipStream_t s) {
+	if (n == 0) return;
+	hipLaunchKernelGGL(k_halo_import, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, s, a, dev_records, n);
+}
+
+// clamp n_halo to the capacity (after an overflow the error flag is set; keep indices in range)
+__global__ void k_halo_clamp(DevCounters* cnt, uint32_t cap) {
+	if (cnt->n_halo_staged > cap) cnt->n_halo_staged = cap;
+}
+
+__global__ void __launch_bounds__(TPB) k_halo_scatter(HaloArgs a) {
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= a.cnt->n_halo_staged) return;
+	const uint32_t k = a.hs.key[i];
+	if (k == KEY_INVALID) return;
+	a.perm[a.cell_begin[k] + a.hs.rank[i] - a.cnt->n_real] = i;
+}
+
+void launch_halo_finalize(const HaloArgs& a, hipStream_t s) {
+	hipLaunchKernelGGL(k_halo_clamp, dim3(1), dim3(1), 0, s, a.cnt, a.cap_halo);
+	run_scan(a.g, a.count, a.blocksum, a.cell_begin, a.cell_end, a.cnt, 1, s);
+	if (a.cap_halo == 0) return;
+	const dim3 grid((a.cap_halo + TPB - 1) / TPB);
+	hipLaunchKernelGGL(k_halo_scatter, grid, dim3(TPB), 0, s, a);
+	if (a.deterministic)
+		hipLaunchKernelGGL(k_cellsort, dim3((a.g.ncells + TPB - 1) / TPB), dim3(TPB), 0, s, a.g, a.cell_begin, a.cell_end,
+						   a.perm, a.hs.id, a.cnt, 1);
+	hipLaunchKernelGGL(k_halo_gather, grid, dim3(TPB), 0, s, a);
+}
+
+}  // namespace ls1

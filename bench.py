@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py — particle-updates/s of the linked-cell pair-force hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one full time step of the hot path (Leapfrog pre-force kick+drift -> re-bin -> halo -> pair forces ->
+post-force kick) over the synthetic liquid of BASELINE.json configs[1]: single-centre Lennard-Jones, rho*=0.785302672,
+rc=2.5 sigma, T*=0.95, dt=0.002, N = 2*171^3 = 10 000 422 per GPU (weak scaling), FP64.  Inputs are resident in HBM
+before the timed region.  Prints ONE JSON line (rank 0) with `roofline` (force kernel: algorithmic bytes / HIP-event
+kernel time vs 8 TB/s) and `cpu_baseline` (the REAL reference binary oracle/_ref/MarDyn timed on the host cores on a
+bounded sample of the same workload; the oracle restatement is used only if that binary is absent).
+"""
+import argparse
+import importlib
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+RHO = 0.785302672
+RC = 2.5
+DT = 0.002
+TEMP = 0.95
+FORCE_BYTES_PER_MOLECULE = 48.0   # read r (24 B) + write F (24 B): SURVEY.md 8(d)
+STEP_BYTES_PER_MOLECULE = 292.0   # full step: force 48 + integrator 120 + re-bin 124
+HBM_PEAK_GBS = 8000.0
+
+
+def bcc_box(n_per_dim, seed=1234, jitter=0.1):
+    """Jittered bcc lattice (ParticleCellBase::initCubicGrid layout, /root/reference/src/particleContainer/
+    ParticleCellBase.cpp:73-177) with Maxwell velocities at T*."""
+    rng = np.random.default_rng(seed)
+    n = n_per_dim
+    N = 2 * n ** 3
+    L = (N / RHO) ** (1.0 / 3.0)
+    a = L / n
+    ax = (np.arange(n, dtype=np.float64) + 0.25) * a
+    g = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    r = np.concatenate([g, g + 0.5 * a])
+    r += jitter * (rng.random(r.shape) - 0.5)
+    r %= L
+    r[r >= L] = 0.0
+    v = rng.standard_normal(r.shape) * np.sqrt(TEMP)
+    v -= v.mean(0)
+    return L, r, v
+
+
+def lj_components(inp):
+    return inp.ComponentSet([inp.make_component(lj=[(0., 0., 0., 1., 1., 1., RC, 0)])], np.zeros((0, 2)), 1e10)
+
+
+MARDYN_XML = """<?xml version='1.0' encoding='UTF-8'?>
+<mardyn version="20100525">
+  <refunits type="SI"><length unit="nm">0.1</length><mass unit="u">1</mass><energy unit="K">1</energy></refunits>
+  <simulation type="MD">
+    <integrator type="Leapfrog"><timestep unit="reduced">{dt}</timestep></integrator>
+    <run><currenttime>0</currenttime><production><steps>{steps}</steps></production></run>
+    <ensemble type="NVT">
+      <temperature unit="reduced">{temp}</temperature>
+      <domain type="box"><lx>{L}</lx><ly>{L}</ly><lz>{L}</lz></domain>
+      <components>
+        <moleculetype id="1" name="1CLJ">
+          <site type="LJ126" id="1"><coords><x>0.0</x><y>0.0</y><z>0.0</z></coords><mass>1.0</mass><sigma>1.0</sigma><epsilon>1.0</epsilon><shifted>0</shifted></site>
+          <momentsofinertia rotaxes="xyz"><Ixx>0.0</Ixx><Iyy>0.0</Iyy><Izz>0.0</Izz></momentsofinertia>
+        </moleculetype>
+      </components>
+      <phasespacepoint><generator name="CubicGridGenerator"><specification>density</specification><density>{rho}</density><binaryMixture>false</binaryMixture></generator></phasespacepoint>
+    </ensemble>
+    <algorithm>
+      <parallelisation type="DomainDecomposition"></parallelisation>
+      <datastructure type="LinkedCells"><cellsInCutoffRadius>1</cellsInCutoffRadius></datastructure>
+      <cutoffs type="CenterOfMass"><radiusLJ unit="reduced">{rc}</radiusLJ></cutoffs>
+      <electrostatic type="ReactionField"><epsilon>1.0e+10</epsilon></electrostatic>
+    </algorithm>
+    <output></output>
+  </simulation>
+</mardyn>
+"""
+
+
+def cpu_baseline(n_per_dim=50, steps=10, budget_s=150):
+    """Reference OpenMP CPU path on the host cores: same liquid (bcc lattice start from the reference's own
+    CubicGridGenerator), bounded sample N = 2*n^3, `steps` steps."""
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("LS1_BENCH_CPU_THREADS", "16")))
+    N = 2 * n_per_dim ** 3
+    L = (N / RHO) ** (1.0 / 3.0)
+    binary = os.path.join(ROOT, "oracle", "_ref", "MarDyn")
+    if os.path.exists(binary):
+        with tempfile.TemporaryDirectory() as td:
+            cfg = os.path.join(td, "config.xml")
+            with open(cfg, "w") as fh:
+                fh.write(MARDYN_XML.format(dt=DT, steps=steps, temp=TEMP, L=repr(L), rho=RHO, rc=RC))
+            env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="close", OMP_PLACES="cores")
+            try:
+                out = subprocess.run([binary, cfg, "--steps", str(steps), "--final-checkpoint=0"], cwd=td, env=env,
+                                     capture_output=True, text=True, timeout=budget_s).stdout
+            except subprocess.TimeoutExpired:
+                out = ""
+            m = re.search(r"Simulation speed:\s*([0-9.eE+-]+)\s*Molecule-updates per second", out)
+            nm = re.search(r"[Nn]umber of molecules[^0-9]*([0-9]+)", out)
+            if m:
+                return {"value": float(m.group(1)), "unit": "particle-updates/s", "cores": cores, "kind": "reference",
+                        "sample": f"reference MarDyn (AVX2, OpenMP c08, FP64) 1CLJ N={nm.group(1) if nm else N} bcc rho*={RHO} rc={RC}, {steps} steps, {cores} threads"}
+    # fallback: the oracle restatement (scalar, 1 core) — only when the reference binary did not travel
+    from oracle.oracle import Oracle  # checker, used here only as the timed CPU baseline
+    inp = importlib.import_module("ls1-mardyn_amd.inp")
+    Lb, r, v = bcc_box(20)
+    n = len(r)
+    orc = Oracle(lj_components(inp).flat(), RC)
+    cid = np.zeros(n, np.int32); q = np.tile([1., 0, 0, 0], (n, 1)); D = np.zeros((n, 3))
+    out = orc.forces(r, q, cid, [Lb] * 3, True)
+    F, M = out["F"].copy(), out["M"].copy()
+    t0 = time.time()
+    ksteps = 3
+    for _ in range(ksteps):
+        orc.step(DT, cid, r, v, q, D, F, M, np.array([Lb] * 3), True)
+    dt = time.time() - t0
+    return {"value": n * ksteps / dt, "unit": "particle-updates/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/ls1_oracle.c scalar restatement, 1CLJ N={n}, {ksteps} steps, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n-per-dim", type=int, default=171, help="bcc cells per dimension per GPU (N = 2 n^3)")
+    ap.add_argument("--kernel", type=int, default=0, help="force kernel variant (LS1HIP_FK_*)")
+    ap.add_argument("--cic", type=int, default=0, help="cells in cutoff (0 = engine default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+
+    import torch
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+
+    inp = importlib.import_module("ls1-mardyn_amd.inp")
+    comps = lj_components(inp)
+    n = args.n_per_dim
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        decomp = importlib.import_module("ls1-mardyn_amd.decomp")
+        sim = decomp.build_weak_scaling_box(comps, RC, n, world, rank, local_rank, bcc_box, cic=args.cic or None,
+                                            kernel=args.kernel)
+        n_total = sim.n_global
+    else:
+        engine_mod = importlib.import_module("ls1-mardyn_amd.engine")
+        L, r, v = bcc_box(n)
+        eng = engine_mod.DeviceEngine(local_rank)
+        eng.set_components(comps, RC)
+        if args.cic:
+            eng.set_option("cells_in_cutoff", args.cic)
+        eng.set_option("force_kernel", args.kernel)
+        eng.set_domain([L, L, L])
+        N = len(r)
+        eng.upload(np.arange(1, N + 1, dtype=np.uint64), np.zeros(N, np.int32), r, v)
+        del r, v
+        eng.rebin(); eng.halo(); eng.forces(0)
+        sim = None
+        n_total = N
+
+    def run(k):
+        if sim is not None:
+            return sim.run(DT, k)
+        return eng.run(DT, k)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(args.warmup)
+    e = sim.engine if sim is not None else eng
+    e.timing_reset()
+    e.timing_enable(True)
+    sync()
+    t0 = time.perf_counter()
+    last = run(args.steps)
+    sync()
+    elapsed = time.perf_counter() - t0
+    e.timing_enable(False)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    force_ms, force_n = e.timing("force")
+    integ_ms, _ = e.timing("integrate")
+    rebin_ms, _ = e.timing("rebin")
+    halo_ms, _ = e.timing("halo")
+    n_local = e.count()[0]
+    if rank == 0:
+        avg_force_s = force_ms / 1e3 / max(force_n, 1)
+        achieved = FORCE_BYTES_PER_MOLECULE * n_local / avg_force_s / 1e9
+        value = n_total * args.steps / elapsed
+        out = {
+            "metric": "particle-updates/sec (whole node), 1CLJ liquid Argon-like LJ, rc=2.5 sigma",
+            "value": value, "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"1CLJ Lennard-Jones liquid, N={n_total} (2*{n}^3 per GPU), rho*={RHO}, rc={RC} sigma, "
+                                   f"dt={DT}, T*={TEMP}, NVE full time step (kick-drift, re-bin, halo, forces, kick), FP64",
+                       "molecules_per_gpu": n_local, "decomposition": getattr(sim, "grid_desc", "single GPU, periodic images local"),
+                       "force_kernel": e.get_option("force_kernel"), "cells_in_cutoff": e.get_option("cells_in_cutoff")},
+            "roofline": {"bound": "hbm", "kernel": "pair-force traversal (k_force_*)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg_force_s * 1e3, "launches": int(force_n),
+                         "algorithmic_bytes_per_launch": FORCE_BYTES_PER_MOLECULE * n_local,
+                         "full_step_frac": STEP_BYTES_PER_MOLECULE * n_total / world * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
+            "device_ms_per_step": {"force": force_ms / args.steps, "integrate": integ_ms / args.steps,
+                                   "rebin": rebin_ms / args.steps, "halo": halo_ms / args.steps},
+            "last_step": {k: (float(v_) if not isinstance(v_, int) else v_) for k, v_ in last.items()} if isinstance(last, dict) else None,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

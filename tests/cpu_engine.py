@@ -1,0 +1,149 @@
+"""Numpy stand-in for DeviceEngine used ONLY by the CPU (gloo) tests of the multi-rank exchange protocol.
+
+It implements the engine surface decomp.HaloExchanger / DistributedSimulation need (export_counts, export_pack,
+import_records, import_done, rebin, halo, forces, kick_drift, kick, count) for single-centre LJ with brute-force
+numpy pair sums.  Record formats and the shift / neighbour rules follow include/ls1hip.h.  Test infrastructure —
+the product never imports it.
+"""
+import ctypes
+
+import numpy as np
+
+
+class CpuEngine:
+    def __init__(self, global_len, bmin, bmax, my_rank, nbr, rc, eps24=24.0, sig2=1.0, mass=1.0):
+        self.L = np.asarray(global_len, float); self.bmin = np.asarray(bmin, float); self.bmax = np.asarray(bmax, float)
+        self.rank = my_rank; self.nbr = np.asarray(nbr); self.rc = rc
+        self.eps24, self.sig2, self.mass = eps24, sig2, mass
+        self.shift = np.zeros((27, 3))
+        for sz in (-1, 0, 1):
+            for sy in (-1, 0, 1):
+                for sx in (-1, 0, 1):
+                    d = (sz + 1) * 9 + (sy + 1) * 3 + (sx + 1)
+                    for k, s in enumerate((sx, sy, sz)):
+                        if s < 0 and self.bmin[k] == 0.0:
+                            self.shift[d, k] = self.L[k]
+                        if s > 0 and self.bmax[k] == self.L[k]:
+                            self.shift[d, k] = -self.L[k]
+        self.exp = {0: [np.zeros((0, 15))] * 27, 1: [np.zeros((0, 9))] * 27}
+        self.pending = []
+        self.halo_r = np.zeros((0, 3))
+        self.F = None
+        self.macro = np.zeros(2)
+
+    def upload(self, ids, r, v):
+        self.ids = np.asarray(ids, np.uint64).copy(); self.r = np.array(r, float); self.v = np.array(v, float)
+        self.F = np.zeros_like(self.r)
+
+    def count(self):
+        return len(self.ids), len(self.halo_r)
+
+    def _dir(self, s):
+        return (s[2] + 1) * 9 + (s[1] + 1) * 3 + (s[0] + 1)
+
+    # --- step pieces
+    def kick_drift(self, dt):
+        self.v += 0.5 * dt / self.mass * self.F
+        self.r += dt * self.v
+
+    def rebin(self):
+        s = np.where(self.r < self.bmin, -1, np.where(self.r >= self.bmax, 1, 0))
+        out = [[] for _ in range(27)]
+        keep = np.ones(len(self.r), bool)
+        for i in np.nonzero(np.any(s != 0, axis=1))[0]:
+            d = self._dir(s[i]); dest = self.nbr[d]
+            if dest == self.rank:
+                self.r[i] += self.shift[d]
+            else:
+                assert dest >= 0
+                rec = np.zeros(15)
+                rec[0] = np.array([self.ids[i]], np.uint64).view(np.float64)[0]
+                rec[1] = np.array([0], np.int64).view(np.float64)[0]
+                rec[2:5] = self.r[i] + self.shift[d]; rec[5:8] = self.v[i]; rec[8] = 1.0
+                out[d].append(rec); keep[i] = False
+        self.ids, self.r, self.v = self.ids[keep], self.r[keep], self.v[keep]
+        self.exp[0] = [np.array(o).reshape(-1, 15) for o in out]
+        self.pending = []
+
+    def halo(self):
+        out = [[] for _ in range(27)]
+        self.pending = []
+        lo = self.r < self.bmin + self.rc
+        hi = self.r >= self.bmax - self.rc
+        for sz in (-1, 0, 1):
+            for sy in (-1, 0, 1):
+                for sx in (-1, 0, 1):
+                    if sx == sy == sz == 0:
+                        continue
+                    s = (sx, sy, sz); d = self._dir(s); dest = self.nbr[d]
+                    if dest < 0:
+                        continue
+                    m = np.ones(len(self.r), bool)
+                    for k in range(3):
+                        if s[k] < 0: m &= lo[:, k]
+                        if s[k] > 0: m &= hi[:, k]
+                    rr = self.r[m] + self.shift[d]
+                    if dest == self.rank:
+                        self.pending.append(rr)
+                    else:
+                        rec = np.zeros((len(rr), 9))
+                        rec[:, 0] = self.ids[m].view(np.float64); rec[:, 2:5] = rr; rec[:, 5] = 1.0
+                        out[d] = rec
+        self.exp[1] = [np.asarray(o).reshape(-1, 9) for o in out]
+
+    def export_counts(self, kind):
+        return np.array([len(x) for x in self.exp[kind]], dtype=np.uint64)
+
+    @staticmethod
+    def _view(ptr, n):
+        return np.ctypeslib.as_array((ctypes.c_double * n).from_address(ptr))
+
+    def export_pack(self, kind, d, ptr, cap):
+        rec = self.exp[kind][d]
+        assert cap >= len(rec)
+        self._view(ptr, rec.size)[:] = rec.reshape(-1)
+
+    def import_records(self, kind, ptr, n):
+        w = 15 if kind == 0 else 9
+        rec = self._view(ptr, n * w).reshape(n, w).copy()
+        if kind == 0:
+            self.ids = np.concatenate([self.ids, rec[:, 0].copy().view(np.uint64)])
+            self.r = np.concatenate([self.r, rec[:, 2:5]]); self.v = np.concatenate([self.v, rec[:, 5:8]])
+        else:
+            self.pending.append(rec[:, 2:5])
+
+    def import_done(self, kind):
+        if kind == 0:
+            assert np.all(self.r >= self.bmin) and np.all(self.r < self.bmax)
+            self.F = np.zeros_like(self.r)
+        else:
+            self.halo_r = np.concatenate(self.pending) if self.pending else np.zeros((0, 3))
+
+    def finalize_local(self):  # single-rank convenience
+        self.import_done(0); self.import_done(1)
+
+    def forces(self, which=0, want_macro=True):
+        if which == 1:
+            return None  # the stand-in does all the work in the boundary call
+        allr = np.concatenate([self.r, self.halo_r])
+        n = len(self.r)
+        F = np.zeros((n, 3)); u6 = 0.0; vir = 0.0
+        rc2 = self.rc ** 2
+        for i in range(n):
+            d = self.r[i] - allr
+            r2 = (d * d).sum(1)
+            m = (r2 < rc2) & (r2 > 0)
+            inv = 1.0 / r2[m]
+            lj6 = (self.sig2 * inv) ** 3; lj12 = lj6 * lj6
+            fac = self.eps24 * (2 * lj12 - lj6) * inv
+            f = d[m] * fac[:, None]
+            F[i] = f.sum(0)
+            u6 += 0.5 * (self.eps24 * (lj12 - lj6)).sum()
+            vir += 0.5 * (d[m] * f).sum()
+        self.F = F
+        self.macro = np.array([u6 / 6.0, vir])
+        return (self.macro[0], self.macro[1]) if want_macro else None
+
+    def kick(self, dt_half, want_sums=True):
+        self.v += dt_half / self.mass * self.F
+        return (float(self.mass * (self.v ** 2).sum()), 0.0, len(self.v), 0) if want_sums else None

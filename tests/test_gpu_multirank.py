@@ -1,0 +1,128 @@
+"""GPU test of the DEVICE side of the multi-rank path on ONE GPU: R DeviceEngine contexts (2, 4, 8 sub-boxes) live in
+one process on cuda:0; the transport is replaced by direct device-buffer hand-over (export_pack -> import), so the
+leaving/halo packing kernels, receiver-frame shifts, import + re-bin and the inner/boundary force split are checked
+against the single-domain result.  (The torch.distributed protocol itself is covered under gloo in
+tests/test_decomp_cpu.py; real RCCL needs one GPU per rank and is exercised by bench.py --gpus N.)"""
+import numpy as np
+import pytest
+
+from conftest import load_pkg
+
+pytestmark = pytest.mark.gpu
+
+decomp = load_pkg("decomp")
+engine_mod = load_pkg("engine")
+inp = load_pkg("inp")
+
+
+class InProcessCluster:
+    def __init__(self, world, comps, rc, L, ids, r, v, grid=None, kernel=0):
+        import torch
+        self.torch = torch
+        self.world = world
+        self.dcs = [decomp.CartesianDecomposition(world, k, L, grid) for k in range(world)]
+        self.eng = []
+        for dc in self.dcs:
+            lo, hi = dc.bounding_box()
+            e = engine_mod.DeviceEngine(0)
+            e.set_components(comps, rc)
+            e.set_option("force_kernel", kernel)
+            e.set_domain(L, lo, hi, dc.rank, dc.neighbor_table())
+            m = np.all((r >= lo) & (r < hi), axis=1)
+            e.upload(ids[m], np.zeros(m.sum(), np.int32), r[m], v[m])
+            self.eng.append(e)
+
+    def exchange(self, kind):
+        torch = self.torch
+        w = decomp.RECORD_DOUBLES[kind]
+        counts = [e.export_counts(kind) for e in self.eng]
+        bufs = []
+        for k, e in enumerate(self.eng):
+            nbr = self.dcs[k].neighbor_table()
+            for d in range(27):
+                c = int(counts[k][d])
+                if c and nbr[d] != k:
+                    assert nbr[d] >= 0
+                    t = torch.empty(c * w, dtype=torch.float64, device="cuda:0")
+                    e.export_pack(kind, d, t.data_ptr(), c)
+                    bufs.append((int(nbr[d]), t, c))
+        torch.cuda.synchronize()
+        for dest, t, c in bufs:
+            self.eng[dest].import_records(kind, t.data_ptr(), c)
+        for e in self.eng:
+            e.import_done(kind)
+
+    def forces(self, split=True):
+        for e in self.eng:
+            e.rebin()
+        self.exchange(decomp.LEAVING)
+        for e in self.eng:
+            e.halo()
+        if split:
+            for e in self.eng:
+                e.forces(1, want_macro=False)
+        self.exchange(decomp.HALO)
+        tot = np.zeros(2)
+        for e in self.eng:
+            tot += np.array(e.forces(2 if split else 0))
+        return tot
+
+    def step(self, dt):
+        for e in self.eng:
+            e.kick_drift(dt)
+        tot = self.forces()
+        kin = np.zeros(2)
+        for e in self.eng:
+            k = e.kick(0.5 * dt)
+            kin += np.array(k[:2])
+        return tot, kin
+
+    def gather(self):
+        st = [e.download_state() for e in self.eng]
+        fr = [e.download_forces() for e in self.eng]
+        ids = np.concatenate([s["ids"] for s in st])
+        o = np.argsort(ids)
+        return dict(ids=ids[o], r=np.concatenate([s["r"] for s in st])[o], v=np.concatenate([s["v"] for s in st])[o],
+                    F=np.concatenate([f["F"] for f in fr])[o])
+
+
+def _liquid(n, seed=11, rho=0.785302672):
+    rng = np.random.default_rng(seed)
+    N = 2 * n ** 3
+    L = (N / rho) ** (1 / 3)
+    a = L / n
+    g = np.stack(np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij"), -1).reshape(-1, 3) * a
+    r = (np.concatenate([g + 0.25 * a, g + 0.75 * a]) + 0.1 * (rng.random((N, 3)) - 0.5)) % L
+    v = rng.normal(0, 1.0, (N, 3)) * 3.0  # hot: many molecules cross sub-box faces within a few steps
+    v -= v.mean(0)
+    return np.array([L] * 3), r, v
+
+
+@pytest.mark.parametrize("world,grid", [(2, None), (4, None), (8, None), (2, (1, 1, 2))])
+def test_subboxes_equal_single_domain(world, grid):
+    L, r, v = _liquid(16)  # 8192 atoms, L = 21.85: 2x2x2 sub-boxes of 10.9 = 4 cells each
+    rc, dt, nsteps = 2.5, 0.004, 5
+    ids = np.arange(1, len(r) + 1, dtype=np.uint64)
+    comps = inp.ComponentSet([inp.make_component(lj=[(0, 0, 0, 1, 1, 1, rc, 0)])], np.zeros((0, 2)), 1e10)
+    single = InProcessCluster(1, comps, rc, L, ids, r, v)
+    multi = InProcessCluster(world, comps, rc, L, ids, r, v, grid)
+    t1 = single.forces(split=False)
+    tm = multi.forces()
+    a, b = single.gather(), multi.gather()
+    assert np.array_equal(a["ids"], b["ids"])
+    Fmax = np.max(np.abs(a["F"]))
+    assert np.max(np.abs(a["F"] - b["F"])) < 1e-12 * Fmax
+    assert np.allclose(t1, tm, rtol=1e-12)
+    for _ in range(nsteps):
+        t1, k1 = single.step(dt)
+        tm, km = multi.step(dt)
+    a, b = single.gather(), multi.gather()
+    assert np.array_equal(a["ids"], b["ids"])  # nobody lost or duplicated while migrating
+    dr = a["r"] - b["r"]
+    dr -= L * np.round(dr / L)
+    assert np.max(np.abs(dr)) < 1e-11
+    assert np.max(np.abs(a["v"] - b["v"])) < 1e-11 * np.max(np.abs(a["v"]))
+    assert np.allclose(t1, tm, rtol=1e-11)
+    assert np.allclose(k1, km, rtol=1e-12)
+    moved = sum(e.count()[0] for e in multi.eng)
+    assert moved == len(ids)

@@ -880,7 +880,9 @@ extern "C" int ls1hip_import_done(ls1hip_ctx* c, int kind) {
 	if (!c) return LS1HIP_EINVAL;
 	REQUIRE(c, kind == 0 || kind == 1, "kind must be 0 or 1");
 	HIPCHK(c, hipSetDevice(c->device));
+	if (!c->has_remote) return LS1HIP_OK;  // purely local domain: ls1hip_rebin / ls1hip_halo already finished the phase
 	if (kind == 0) {
+		REQUIRE(c, !c->binned, "import_done(0) without a pending ls1hip_rebin");
 		int rc = do_rebin_finish(c, c->pending_in);
 		if (rc) return rc;
 		if ((rc = sync_counters(c))) return rc;

@@ -1,7 +1,369 @@
-// kernels_force_lj.hip — LDS-tiled single-centre LJ force kernel (placeholder until the tiled kernel lands:
-// returns false so the caller uses the generic kernel).
+// kernels_force_lj.hip — the MI355X fast path: brick-tiled, LDS-staged single-centre Lennard-Jones force kernel.
+//
+// Work decomposition (CDNA4: wave64, 160 KB LDS / CU, FP64 VALU at 4 cycles per wave instruction)
+//   * one 256-thread workgroup per BRICK of BX x BY x BZ cells (about 200 molecules at liquid density);
+//   * the brick plus its cutoff shell ((BX+2hw)(BY+2hw)(BZ+2hw) cells, ~1200 molecules) is staged ONCE into LDS
+//     in region-linear order, so every x-row of 2hw+1 neighbour cells is one contiguous LDS range — the
+//     positions of a molecule are read from HBM once per brick instead of once per neighbour;
+//   * one lane per owned molecule i (full shell, no atomics, deterministic):
+//       phase 1  walks the (2hw+1)^2 neighbour rows and appends the in-range j to a per-lane list in LDS
+//                (u16 indices, slot-major so lanes hit consecutive banks) — cheap distance arithmetic only;
+//       phase 2  runs the LJ body over the list: every lane of the wave does useful FP64 work in every
+//                iteration (about 51 of 335 candidates are in range; without the list the 30-instruction body
+//                would run masked-off for the other 85 %).
+//   * U/6 and the virial are reduced per workgroup and summed by a deterministic second pass.
+// Robustness: a brick whose shell does not fit the LDS staging area, or a lane whose list is full, falls back to
+// direct evaluation (same arithmetic), so any density is handled.
+//
+// Arithmetic per pair = VectorizedCellProcessor::_loopBodyLJ (/root/reference/src/particleContainer/adapter/
+// VectorizedCellProcessor.cpp:173-226); masks = CellPairPolicy_/SingleCellPolicy_ (vectorization/
+// SIMD_VectorizedCellProcessorHelpers.h:344-422); the reciprocal is v_rcp_f64 + 2 Newton steps (the reference's
+// own AVX2 path is rcp_ps + 3 Newton steps, RealVecDouble.h:415-434) — parity is tolerance-based (1e-10).
 #include "common.hpp"
 
 namespace ls1 {
-bool launch_force_lj(const ForceParams&, hipStream_t, uint32_t*, double*, size_t) { return false; }
+
+constexpr int LTPB = 256;
+// LDS budget: two workgroups per CU (2 x 80 KB of the 160 KB) = 2 waves per SIMD.
+//   CAPJ  staged molecules per brick region (3 x 8 B each),  CAPL  per-lane neighbour list capacity (u16 each)
+//   hw=1: 1664 x 24 B = 39.9 KB + 72 x 256 x 2 B = 36.9 KB;   hw=2: 1536 x 24 B = 36.9 KB + 64 x 512 B = 32.8 KB (+6.6 KB tables)
+
+__device__ __forceinline__ double fast_rcp(double d) {
+	double x = __builtin_amdgcn_rcp(d);
+	double e = fma(-d, x, 1.0);
+	x = fma(x, e, x);
+	e = fma(-d, x, 1.0);
+	return fma(x, e, x);
+}
+
+struct LjAcc {
+	double fx, fy, fz, u6, vir;
+};
+
+__device__ __forceinline__ void lj_pair(double xi, double yi, double zi, double xj, double yj, double zj, double rc2,
+										double eps24, double sig2, double shift6, LjAcc& a) {
+	const double dx = xi - xj, dy = yi - yj, dz = zi - zj;
+	const double r2 = fma(dz, dz, fma(dy, dy, dx * dx));
+	const bool in = (r2 < rc2) & (r2 != 0.0);
+	const double inv = fast_rcp(in ? r2 : 1.0);
+	const double lj2 = sig2 * inv;
+	const double lj6 = lj2 * lj2 * lj2;
+	const double lj12 = lj6 * lj6;
+	const double lj12m6 = lj12 - lj6;
+	double fac = eps24 * inv * (lj12 + lj12m6);
+	double ut = fma(eps24, lj12m6, shift6);
+	fac = in ? fac : 0.0;
+	ut = in ? ut : 0.0;
+	a.fx = fma(fac, dx, a.fx);
+	a.fy = fma(fac, dy, a.fy);
+	a.fz = fma(fac, dz, a.fz);
+	a.u6 += ut;
+	a.vir = fma(fac, r2, a.vir);
+}
+
+// pair known to be in range and distinct: no masks; the potential is accumulated as sum(lj12 - lj6)
+__device__ __forceinline__ void lj_pair_in(double xi, double yi, double zi, double xj, double yj, double zj, double eps24,
+										   double sig2, LjAcc& a, double& slj) {
+	const double dx = xi - xj, dy = yi - yj, dz = zi - zj;
+	const double r2 = fma(dz, dz, fma(dy, dy, dx * dx));
+	const double inv = fast_rcp(r2);
+	const double lj2 = sig2 * inv;
+	const double lj6 = lj2 * lj2 * lj2;
+	const double lj12 = lj6 * lj6;
+	const double lj12m6 = lj12 - lj6;
+	const double fac = eps24 * inv * (lj12 + lj12m6);
+	a.fx = fma(fac, dx, a.fx);
+	a.fy = fma(fac, dy, a.fy);
+	a.fz = fma(fac, dz, a.fz);
+	slj += lj12m6;
+	a.vir = fma(fac, r2, a.vir);
+}
+
+__device__ __forceinline__ double wave_sum_lj(double v) {
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+	return v;
+}
+
+// block-wide exclusive scan of `n` (<= LTPB*4) u32 values held in LDS array v[0..n) -> v becomes exclusive prefix,
+// v[n] = total.  All threads must call.
+__device__ __forceinline__ void block_scan_lds(uint32_t* v, int n, uint32_t* wsum) {
+	const int t = threadIdx.x;
+	uint32_t a[4], s = 0;
+	for (int k = 0; k < 4; ++k) {
+		const int i = t * 4 + k;
+		a[k] = (i < n) ? v[i] : 0u;
+		s += a[k];
+	}
+	uint32_t inc = s;
+	const int lane = t & 63, w = t >> 6;
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t u = __shfl_up(inc, o);
+		if (lane >= o) inc += u;
+	}
+	if (lane == 63) wsum[w] = inc;
+	__syncthreads();
+	uint32_t base = 0;
+	for (int i = 0; i < w; ++i) base += wsum[i];
+	uint32_t ex = base + inc - s;
+	__syncthreads();
+	for (int k = 0; k < 4; ++k) {
+		const int i = t * 4 + k;
+		if (i < n) v[i] = ex;
+		ex += a[k];
+	}
+	if (t == LTPB - 1) v[n] = ex;  // last thread's running value = total (its items beyond n contribute 0)
+	__syncthreads();
+}
+
+template <int HW, int BX, int BY, int BZ, int CAPJ, int CAPL>
+__global__ void __launch_bounds__(LTPB, 2) k_force_lj_brick(ForceParams P, int nbx, int nby, int nbz) {
+	constexpr int RX = BX + 2 * HW, RY = BY + 2 * HW, RZ = BZ + 2 * HW;
+	constexpr int NRC = RX * RY * RZ;
+	constexpr int NBC = BX * BY * BZ;
+	static_assert(NRC <= LTPB * 4, "region too large for the block scan");
+	__shared__ double sx[CAPJ + 8], sy[CAPJ + 8], sz[CAPJ + 8];  // +8: unrolled reads may run past a row end
+	__shared__ uint16_t lst[(CAPL + 1) * LTPB];  // +1: per-lane dummy slot for branch-free appends
+	__shared__ uint32_t cstart[NRC + 1];  // LDS index of the first molecule of every region cell (region-linear order)
+	__shared__ uint32_t gbeg[NRC];        // global index of the first molecule of every region cell
+	__shared__ uint32_t bstart[NBC + 1];  // prefix over the brick's own cells (i-molecule enumeration)
+	__shared__ uint32_t wsum[LTPB / 64];
+	__shared__ double red[LTPB / 64][2];
+
+	const int tid = threadIdx.x;
+	// XCD-aware brick order: workgroups are dealt round-robin to the 8 XCDs, so give every XCD a contiguous run of
+	// bricks (neighbouring bricks share most of their shell -> they hit the same 4 MB L2).
+	const int nb = nbx * nby * nbz;
+	const int chunk = gridDim.x / 8;  // the grid is 8 * ceil(nb / 8) workgroups
+	const int brick = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
+	bool live = brick < nb;
+	int bx = 0, by = 0, bz = 0;
+	if (live) {
+		bx = brick % nbx;
+		by = (brick / nbx) % nby;
+		bz = brick / (nbx * nby);
+	}
+	// brick origin in grid cell coordinates and its extent (edge bricks are partial)
+	const int x0 = HW + bx * BX, y0 = HW + by * BY, z0 = HW + bz * BZ;
+	const int ex = min(BX, P.g.dims[0] - HW - x0), ey = min(BY, P.g.dims[1] - HW - y0), ez = min(BZ, P.g.dims[2] - HW - z0);
+	if (live && P.which != 0) {
+		// "inner" brick: no halo cell inside its shell (cells [2hw, dims-2hw) in every dimension)
+		const bool inner = x0 >= 2 * HW && y0 >= 2 * HW && z0 >= 2 * HW && x0 + ex <= P.g.dims[0] - 2 * HW &&
+						   y0 + ey <= P.g.dims[1] - 2 * HW && z0 + ez <= P.g.dims[2] - 2 * HW;
+		live = (P.which == 1) ? inner : !inner;
+	}
+	if (!live) {  // uniform per block
+		if (tid < 4) P.partials[(size_t)blockIdx.x * 4 + tid] = 0.;
+		return;
+	}
+
+	// ---- 1. region cell table ------------------------------------------------------------------------------------
+	for (int c = tid; c < NRC; c += LTPB) {
+		const int rx = c % RX, ry = (c / RX) % RY, rz = c / (RX * RY);
+		const int gx = x0 - HW + rx, gy = y0 - HW + ry, gz = z0 - HW + rz;
+		uint32_t b = 0, n = 0;
+		if (gx < P.g.dims[0] && gy < P.g.dims[1] && gz < P.g.dims[2]) {  // lower bounds are >= 0 by construction
+			const int gc = cell_index(P.g, gx, gy, gz);
+			b = P.cell_begin[gc];
+			n = P.cell_end[gc] - b;
+		}
+		gbeg[c] = b;
+		cstart[c] = n;
+	}
+	__syncthreads();
+	block_scan_lds(cstart, NRC, wsum);
+	const uint32_t total = cstart[NRC];
+	// brick cell prefix (own molecules)
+	for (int c = tid; c < NBC; c += LTPB) {
+		const int cx = c % BX, cy = (c / BX) % BY, cz = c / (BX * BY);
+		uint32_t n = 0;
+		if (cx < ex && cy < ey && cz < ez) {
+			const int rcell = ((cz + HW) * RY + (cy + HW)) * RX + (cx + HW);
+			n = cstart[rcell + 1] - cstart[rcell];
+		}
+		bstart[c] = n;
+	}
+	__syncthreads();
+	block_scan_lds(bstart, NBC, wsum);
+	const uint32_t n_i = bstart[NBC];
+	const bool staged = total <= (uint32_t)CAPJ;
+
+	// ---- 2. stage positions (HBM -> LDS, each molecule of the shell read once per brick) ------------------------
+	if (staged) {
+		for (uint32_t s = tid; s < total; s += LTPB) {
+			int lo = 0, hi = NRC;  // largest c with cstart[c] <= s
+			while (hi - lo > 1) {
+				const int mid = (lo + hi) >> 1;
+				if (cstart[mid] <= s) lo = mid;
+				else hi = mid;
+			}
+			const uint32_t g = gbeg[lo] + (s - cstart[lo]);
+			sx[s] = P.x[g];
+			sy[s] = P.y[g];
+			sz[s] = P.z[g];
+		}
+	}
+	__syncthreads();
+
+	const double rc2 = P.rc2, eps24 = P.eps24, sig2 = P.sig2, shift6 = P.shift6;
+	double u6_tot = 0., vir_tot = 0.;
+	for (uint32_t base = 0; base < n_i; base += LTPB) {  // one pass unless the brick is over-full
+		const uint32_t it = base + tid;
+		const bool active = it < n_i;
+		LjAcc acc = {0., 0., 0., 0., 0.};
+		uint32_t gi = 0;
+		if (active) {
+			int lo = 0, hi = NBC;
+			while (hi - lo > 1) {
+				const int mid = (lo + hi) >> 1;
+				if (bstart[mid] <= it) lo = mid;
+				else hi = mid;
+			}
+			const int cx = lo % BX, cy = (lo / BX) % BY, cz = lo / (BX * BY);
+			const int rxc = cx + HW, ryc = cy + HW, rzc = cz + HW;
+			const int rcell = (rzc * RY + ryc) * RX + rxc;
+			const uint32_t k = it - bstart[lo];
+			const uint32_t ii = cstart[rcell] + k;
+			gi = gbeg[rcell] + k;
+			if (staged) {
+				const double xi = sx[ii], yi = sy[ii], zi = sz[ii];
+				uint32_t cnt = 0;  // hits found (may exceed CAPL: then the list is incomplete and the lane re-evaluates directly)
+				// ---- phase 1: candidate rows -> per-lane list.  U candidates per trip, the next trip's 3U LDS reads are
+				// issued before the current trip is processed (register double buffer) so LDS latency overlaps the
+				// distance arithmetic; the append is branch-free (misses / overflow write to a per-lane dummy slot).
+				constexpr int U = 4;
+				const uint32_t lbase = (uint32_t)tid;
+#pragma unroll
+				for (int dz = -HW; dz <= HW; ++dz) {
+#pragma unroll
+					for (int dy = -HW; dy <= HW; ++dy) {
+						const int r0 = ((rzc + dz) * RY + (ryc + dy)) * RX + (rxc - HW);
+						const uint32_t jb = cstart[r0], je = cstart[r0 + 2 * HW + 1];
+						double ax[U], ay[U], az[U], bxv[U], byv[U], bzv[U];
+#pragma unroll
+						for (int u = 0; u < U; ++u) {  // reads past `je` stay inside the padded staging arrays
+							ax[u] = sx[jb + u];
+							ay[u] = sy[jb + u];
+							az[u] = sz[jb + u];
+						}
+						for (uint32_t j0 = jb; j0 < je; j0 += U) {
+#pragma unroll
+							for (int u = 0; u < U; ++u) {
+								bxv[u] = sx[j0 + U + u];
+								byv[u] = sy[j0 + U + u];
+								bzv[u] = sz[j0 + U + u];
+							}
+							const uint32_t nvalid = je - j0;
+#pragma unroll
+							for (int u = 0; u < U; ++u) {
+								const double dx = xi - ax[u], dyy = yi - ay[u], dzz = zi - az[u];
+								const double r2 = fma(dzz, dzz, fma(dyy, dyy, dx * dx));
+								bool hit = (r2 < rc2) & ((uint32_t)u < nvalid);
+								if (dz == 0 && dy == 0) hit &= (j0 + u != ii);  // self lives in the own row only
+								const uint32_t slot = min(hit ? cnt : (uint32_t)CAPL, (uint32_t)CAPL);
+								lst[slot * LTPB + lbase] = (uint16_t)(j0 + u);
+								cnt += hit ? 1u : 0u;
+							}
+#pragma unroll
+							for (int u = 0; u < U; ++u) {
+								ax[u] = bxv[u];
+								ay[u] = byv[u];
+								az[u] = bzv[u];
+							}
+						}
+					}
+				}
+				if (cnt <= (uint32_t)CAPL) {
+					// ---- phase 2: dense LJ evaluation over the list (every entry is in range, no masks), 4 per trip
+					double slj = 0.;
+					uint32_t s2 = 0;
+					for (; s2 + 4 <= cnt; s2 += 4) {
+						uint32_t jj[4];
+#pragma unroll
+						for (int u = 0; u < 4; ++u) jj[u] = lst[(s2 + u) * LTPB + lbase];
+						double px[4], py[4], pz[4];
+#pragma unroll
+						for (int u = 0; u < 4; ++u) {
+							px[u] = sx[jj[u]];
+							py[u] = sy[jj[u]];
+							pz[u] = sz[jj[u]];
+						}
+#pragma unroll
+						for (int u = 0; u < 4; ++u) lj_pair_in(xi, yi, zi, px[u], py[u], pz[u], eps24, sig2, acc, slj);
+					}
+					for (; s2 < cnt; ++s2) {
+						const uint32_t j = lst[s2 * LTPB + lbase];
+						lj_pair_in(xi, yi, zi, sx[j], sy[j], sz[j], eps24, sig2, acc, slj);
+					}
+					acc.u6 = fma(eps24, slj, shift6 * (double)cnt);
+				} else {
+					// list overflow (very dense neighbourhood): direct evaluation of this molecule
+					for (int dz = -HW; dz <= HW; ++dz)
+						for (int dy = -HW; dy <= HW; ++dy) {
+							const int r0 = ((rzc + dz) * RY + (ryc + dy)) * RX + (rxc - HW);
+							const uint32_t jb = cstart[r0], je = cstart[r0 + 2 * HW + 1];
+							for (uint32_t j = jb; j < je; ++j)
+								if (j != ii) lj_pair(xi, yi, zi, sx[j], sy[j], sz[j], rc2, eps24, sig2, shift6, acc);
+						}
+				}
+			} else {
+				// shell does not fit LDS (pathological density): same arithmetic straight from global memory
+				const double xi = P.x[gi], yi = P.y[gi], zi = P.z[gi];
+				for (int dz = -HW; dz <= HW; ++dz)
+					for (int dy = -HW; dy <= HW; ++dy) {
+						const int r0 = ((rzc + dz) * RY + (ryc + dy)) * RX + (rxc - HW);
+						for (int c = r0; c <= r0 + 2 * HW; ++c) {
+							const uint32_t gb = gbeg[c], n = cstart[c + 1] - cstart[c];
+							for (uint32_t j = gb; j < gb + n; ++j)
+								if (j != gi) lj_pair(xi, yi, zi, P.x[j], P.y[j], P.z[j], rc2, eps24, sig2, shift6, acc);
+						}
+					}
+			}
+			P.Fx[gi] = acc.fx;
+			P.Fy[gi] = acc.fy;
+			P.Fz[gi] = acc.fz;
+		}
+		u6_tot += acc.u6;
+		vir_tot += acc.vir;
+	}
+	// every ordered pair contributes half of the pair's U and virial (see kernels_force.hip)
+	double u = wave_sum_lj(0.5 * u6_tot), v = wave_sum_lj(0.5 * vir_tot);
+	const int lane = tid & 63, w = tid >> 6;
+	if (lane == 0) {
+		red[w][0] = u;
+		red[w][1] = v;
+	}
+	__syncthreads();
+	if (tid == 0) {
+		double* out = P.partials + (size_t)blockIdx.x * 4;
+		out[0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+		out[1] = 0.;
+		out[2] = 0.;
+		out[3] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+	}
+}
+
+bool launch_force_lj(const ForceParams& p, hipStream_t s, uint32_t* nblocks, double* partials, size_t partials_cap) {
+	(void)partials;
+	const Grid& g = p.g;
+	if (g.hw == 1) {
+		constexpr int BX = 4, BY = 2, BZ = 2;
+		const int nbx = (g.box[0] + BX - 1) / BX, nby = (g.box[1] + BY - 1) / BY, nbz = (g.box[2] + BZ - 1) / BZ;
+		const long nb = 8 * (((long)nbx * nby * nbz + 7) / 8);
+		if (nb <= 0 || (size_t)nb > partials_cap || nb > 0x7fffffffL) return false;
+		*nblocks = (uint32_t)nb;
+		hipLaunchKernelGGL((k_force_lj_brick<1, BX, BY, BZ, 1656, 71>), dim3((uint32_t)nb), dim3(LTPB), 0, s, p, nbx, nby, nbz);
+		return true;
+	}
+	if (g.hw == 2) {
+		constexpr int BX = 8, BY = 4, BZ = 4;
+		const int nbx = (g.box[0] + BX - 1) / BX, nby = (g.box[1] + BY - 1) / BY, nbz = (g.box[2] + BZ - 1) / BZ;
+		const long nb = 8 * (((long)nbx * nby * nbz + 7) / 8);
+		if (nb <= 0 || (size_t)nb > partials_cap || nb > 0x7fffffffL) return false;
+		*nblocks = (uint32_t)nb;
+		hipLaunchKernelGGL((k_force_lj_brick<2, BX, BY, BZ, 1528, 63>), dim3((uint32_t)nb), dim3(LTPB), 0, s, p, nbx, nby, nbz);
+		return true;
+	}
+	return false;
+}
+
 }  // namespace ls1

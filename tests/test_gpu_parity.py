@@ -284,3 +284,70 @@ def test_seam_a_soa_forces_matches_reference():
     assert rel_max(M, g["recs"]["M"]) < TOL
     assert abs(out["upot"] - g["upot"]) <= TOL * abs(g["upot"])
     assert abs(out["virial"] - g["virial"]) <= TOL * abs(g["virial"])
+
+
+# ---- the LDS-tiled single-centre LJ kernel (kernels_force_lj.hip) ------------------------------------------------
+LJ1_CASES = ["U0", "F0", "U0_periodic", "lj1clj", "bcc1clj_3456", "bcc1clj_16000"]
+
+
+@pytest.mark.parametrize("cic", [1, 2])
+@pytest.mark.parametrize("name", LJ1_CASES)
+def test_lds_kernel_matches_reference_golden(name, cic):
+    case = MAN[name]
+    g = read_golden(name)
+    ps = inp.read_inp(input_path(case["input"]))
+    st = sorted_phase_space(ps)
+    if cic == 2 and np.min(ps.length) < 2 * case["rc"] * 0.5 * 2:
+        pass  # tiny boxes still work with half-size cells (at least one cell per dimension)
+    out = run_forces(ps, st, case["rc"], bool(case["periodic"]), kernel=capi.FK_LDS_LIST, vi=False, cic=cic)
+    assert out["container"].engine.get_option("force_kernel") == capi.FK_LDS_LIST
+    rec = g["recs"]
+    fl = FORCE_FLOOR.get(name, 0.0)
+    assert rel_max(out["F"], rec["F"], fl) < TOL
+    assert abs(out["upot"] - g["upot"]) <= TOL * max(abs(g["upot"]), 1e-300) or abs(out["upot"] - g["upot"]) < 1e-12
+    assert abs(out["virial"] - g["virial"]) <= TOL * max(abs(g["virial"]), 1e-300) or abs(out["virial"] - g["virial"]) < 1e-9
+
+
+def test_lds_kernel_equals_generic_kernel_large_box():
+    """N = 250 000: LDS-list kernel vs the generic kernel (same inputs): forces to 1e-13, sums to 1e-12; also the
+    inner/boundary split and run-to-run bitwise reproducibility of the LDS kernel."""
+    L, r, v = _bcc(50, seed=7)
+    N = len(r)
+    comp = inp.ComponentSet([inp.make_component(lj=[(0, 0, 0, 1, 1, 1, 2.5, 0)])], np.zeros((0, 2)), 1e10)
+    ps = inp.PhaseSpace(comp, np.array([L, L, L]), np.arange(1, N + 1, dtype=np.uint64), np.zeros(N, np.int32),
+                        r, v, np.tile([1., 0, 0, 0], (N, 1)), np.zeros((N, 3)))
+    st = sorted_phase_space(ps)
+    gen = run_forces(ps, st, 2.5, True, kernel=capi.FK_GENERIC, vi=False)
+    for cic in (1, 2):
+        lds = run_forces(ps, st, 2.5, True, kernel=capi.FK_LDS_LIST, vi=False, cic=cic)
+        assert rel_max(lds["F"], gen["F"]) < 1e-13
+        assert abs(lds["upot"] - gen["upot"]) < 1e-12 * abs(gen["upot"])
+        assert abs(lds["virial"] - gen["virial"]) < 1e-12 * abs(gen["virial"])
+        again = run_forces(ps, st, 2.5, True, kernel=capi.FK_LDS_LIST, vi=False, cic=cic)
+        assert np.array_equal(again["F"], lds["F"]) and again["upot"] == lds["upot"]
+        cont = lds["container"]
+        dom = mirror.Domain(ps.length)
+        cp = mirror.VectorizedCellProcessor(dom, 2.5, 2.5)
+        cont.traversePartialInnermostCells(cp, 0, 1)
+        cont.traverseNonInnermostCells(cp)
+        mol = cont.molecules()
+        F = cont.forces()["F"][np.argsort(mol["ids"])]
+        assert np.array_equal(F, lds["F"])
+        assert abs(dom.getLocalUpot() - lds["upot"]) <= 1e-13 * abs(lds["upot"])
+
+
+def test_lds_kernel_dense_cluster_fallbacks():
+    """Pathological density: 3000 atoms in a few cells (list overflow + shell larger than the LDS staging area)
+    must still match the generic kernel."""
+    rng = np.random.default_rng(9)
+    L = 12.0
+    r = np.concatenate([rng.uniform(3.0, 6.0, (3000, 3)), rng.uniform(0, L, (500, 3))])
+    N = len(r)
+    comp = inp.ComponentSet([inp.make_component(lj=[(0, 0, 0, 1, 1e-3, 0.3, 2.5, 0)])], np.zeros((0, 2)), 1e10)
+    ps = inp.PhaseSpace(comp, np.array([L, L, L]), np.arange(1, N + 1, dtype=np.uint64), np.zeros(N, np.int32),
+                        r, np.zeros((N, 3)), np.tile([1., 0, 0, 0], (N, 1)), np.zeros((N, 3)))
+    st = sorted_phase_space(ps)
+    gen = run_forces(ps, st, 2.5, True, kernel=capi.FK_GENERIC, vi=False)
+    lds = run_forces(ps, st, 2.5, True, kernel=capi.FK_LDS_LIST, vi=False)
+    assert rel_max(lds["F"], gen["F"]) < 1e-12
+    assert abs(lds["upot"] - gen["upot"]) < 1e-12 * abs(gen["upot"])

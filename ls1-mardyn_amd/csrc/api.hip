@@ -96,7 +96,7 @@ static void free_mol(ls1hip_ctx* c) {
 	HaloStage& h = c->hs;
 	dfree(h.x); dfree(h.y); dfree(h.z); dfree(h.q0); dfree(h.q1); dfree(h.q2); dfree(h.q3); dfree(h.id); dfree(h.cid);
 	dfree(h.key); dfree(h.rank);
-	dfree(c->d_key); dfree(c->d_rank); dfree(c->d_perm); dfree(c->d_ckey);
+	dfree(c->d_key); dfree(c->d_rank); dfree(c->d_perm); dfree(c->d_ckey); dfree(c->d_idk);
 	dfree(c->d_partials);
 	dfree(c->d_exp_leave); dfree(c->d_exp_halo);
 	c->cap_real = c->cap_halo = 0;
@@ -135,6 +135,7 @@ extern "C" int ls1hip_create(int device, ls1hip_ctx** out) {
 	if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess ||
 		(e = hipMalloc((void**)&c->d_ct, sizeof(CompTable))) != hipSuccess ||
 		(e = hipMalloc((void**)&c->d_cnt, sizeof(DevCounters))) != hipSuccess ||
+		(e = hipMalloc((void**)&c->d_stage, 128 * 4 * sizeof(double))) != hipSuccess ||
 		(e = hipHostMalloc((void**)&c->h_cnt, sizeof(DevCounters))) != hipSuccess ||
 		(e = hipMemset(c->d_cnt, 0, sizeof(DevCounters))) != hipSuccess) {
 		g_create_err = std::string("context setup failed: ") + hipGetErrorString(e);
@@ -153,6 +154,7 @@ extern "C" int ls1hip_destroy(ls1hip_ctx* c) {
 	free_cells(c);
 	dfree(c->d_ct);
 	dfree(c->d_cnt);
+	dfree(c->d_stage);
 	if (c->h_cnt) hipHostFree(c->h_cnt);
 	timer_free(c->t_force); timer_free(c->t_integrate); timer_free(c->t_rebin); timer_free(c->t_halo);
 	hipStreamDestroy(c->stream);
@@ -427,7 +429,8 @@ static int alloc_mol(ls1hip_ctx* c, size_t n) {
 			(rc = dalloc(c, &h.q3, cap_halo));
 	if (rc) return rc;
 	(rc = dalloc(c, &c->d_key, cap_real)) || (rc = dalloc(c, &c->d_rank, cap_real)) ||
-		(rc = dalloc(c, &c->d_perm, std::max(cap_real, cap_halo))) || (rc = dalloc(c, &c->d_ckey, cap_real));
+		(rc = dalloc(c, &c->d_perm, std::max(cap_real, cap_halo))) || (rc = dalloc(c, &c->d_ckey, cap_real)) ||
+		(rc = dalloc(c, &c->d_idk, cap_real));
 	if (rc) return rc;
 	c->partials_cap = cap_real / 64 + 16;
 	if ((rc = dalloc(c, &c->d_partials, c->partials_cap * 4))) return rc;
@@ -561,7 +564,7 @@ static RebinArgs rebin_args(ls1hip_ctx* c, uint32_t n_in) {
 	a.src = c->mol[c->cur];
 	a.dst = c->mol[c->cur ^ 1];
 	a.has_rot = c->h_ct.has_rot;
-	a.key = c->d_key; a.rank = c->d_rank; a.perm = c->d_perm; a.ckey = c->d_ckey;
+	a.key = c->d_key; a.rank = c->d_rank; a.perm = c->d_perm; a.ckey = c->d_ckey; a.idk = c->d_idk;
 	a.count = c->d_count; a.cell_begin = c->d_cell_begin; a.cell_end = c->d_cell_end; a.blocksum = c->d_blocksum;
 	a.cnt = c->d_cnt;
 	a.n_in = n_in;
@@ -665,7 +668,7 @@ static int launch_forces(ls1hip_ctx* c, int which) {
 			FAIL(c, LS1HIP_EINVAL, "force_kernel=LDS_LIST supports single-centre LJ components only");
 		launch_force_generic(P, c->one_clj, c->opt_vi != 0, c->h_ct.has_rot != 0, c->stream, &nblocks);
 	}
-	launch_force_reduce(c->d_cnt, c->d_partials, nblocks, c->stream);
+	launch_force_reduce(c->d_cnt, c->d_partials, nblocks, c->d_stage, c->stream);
 	return LS1HIP_OK;
 }
 
@@ -1035,7 +1038,7 @@ extern "C" int ls1hip_soa_forces(ls1hip_ctx* c, const int cell_dims[3], const ui
 	launch_clear_macro(c->d_cnt, c->stream);
 	if (n) {
 		launch_force_generic(P, c->one_clj, true, rot, c->stream, &nblocks);
-		launch_force_reduce(c->d_cnt, part, nblocks, c->stream);
+		launch_force_reduce(c->d_cnt, part, nblocks, c->d_stage, c->stream);
 	}
 	rc = sync_counters(c);
 	if (!rc) {

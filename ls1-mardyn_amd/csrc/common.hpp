@@ -108,11 +108,13 @@ struct ls1hip_ctx {
 	ls1::ForceSoA frc;
 	ls1::HaloStage hs;
 	uint32_t *d_key = nullptr, *d_rank = nullptr, *d_perm = nullptr, *d_ckey = nullptr;
+	uint64_t* d_idk = nullptr;
 	uint32_t *d_count = nullptr, *d_cell_begin = nullptr, *d_cell_end = nullptr, *d_blocksum = nullptr;
 	size_t cells_alloc = 0;
 	ls1::DevCounters* d_cnt = nullptr;
 	ls1::DevCounters* h_cnt = nullptr;  // pinned mirror
 	double* d_partials = nullptr;
+	double* d_stage = nullptr;  // [128][4] second-stage reduction buffer
 	size_t partials_cap = 0;
 	double* d_exp_leave = nullptr;  // per-direction slices, LS1HIP_LEAVING_DOUBLES per record
 	double* d_exp_halo = nullptr;   // per-direction slices, LS1HIP_HALO_DOUBLES per record
@@ -132,6 +134,7 @@ struct RebinArgs {
 	MolSoA src, dst;
 	bool has_rot;
 	uint32_t *key, *rank, *perm, *ckey, *count, *cell_begin, *cell_end, *blocksum;
+	uint64_t* idk;  // molecule ids in slot order (canonical in-cell ordering)
 	DevCounters* cnt;
 	uint32_t n_in;      // molecules in src (launch bound)
 	int nbr[27];
@@ -170,7 +173,7 @@ void launch_pack_copy(double* dst, const double* src, uint32_t ndoubles, hipStre
 void launch_force_generic(const ForceParams& p, bool one_clj, bool with_vi, bool has_rot, hipStream_t s, uint32_t* nblocks);
 // LDS-tiled 1CLJ kernel (kernels_force_lj.hip); returns false if it cannot handle the configuration
 bool launch_force_lj(const ForceParams& p, hipStream_t s, uint32_t* nblocks, double* partials, size_t partials_cap);
-void launch_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, hipStream_t s);
+void launch_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, double* stage, hipStream_t s);
 void launch_clear_macro(DevCounters* cnt, hipStream_t s);
 
 struct IntegArgs {

@@ -179,10 +179,12 @@ void launch_force_generic(const ForceParams& p, bool one_clj, bool with_vi, bool
 	}
 }
 
-// deterministic second pass: one block sums the per-block partials in fixed order and ADDS them to cnt->macro
-__global__ void __launch_bounds__(256) k_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks) {
+// deterministic reduction of the per-workgroup partials in two fixed-shape stages (RED_BLOCKS x 256 threads, then one
+// block), ADDED to cnt->macro; the summation order depends only on the number of partials, never on timing.
+constexpr int RED_BLOCKS = 128;
+__global__ void __launch_bounds__(256) k_force_reduce1(const double* partials, uint32_t nblocks, double* stage) {
 	double v[4] = {0., 0., 0., 0.};
-	for (uint32_t b = threadIdx.x; b < nblocks; b += 256)
+	for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < nblocks; b += RED_BLOCKS * 256)
 		for (int k = 0; k < 4; ++k) v[k] += partials[(size_t)b * 4 + k];
 	__shared__ double red[4][4];
 	for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
@@ -190,12 +192,28 @@ __global__ void __launch_bounds__(256) k_force_reduce(DevCounters* cnt, const do
 	if (lane == 0)
 		for (int k = 0; k < 4; ++k) red[w][k] = v[k];
 	__syncthreads();
-	if (threadIdx.x < 4) cnt->macro[threadIdx.x] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+	if (threadIdx.x < 4) stage[blockIdx.x * 4 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void __launch_bounds__(RED_BLOCKS) k_force_reduce2(DevCounters* cnt, const double* stage) {
+	double v[4];
+	for (int k = 0; k < 4; ++k) v[k] = stage[threadIdx.x * 4 + k];
+	__shared__ double red[RED_BLOCKS / 64][4];
+	for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	if (lane == 0)
+		for (int k = 0; k < 4; ++k) red[w][k] = v[k];
+	__syncthreads();
+	if (threadIdx.x < 4) {
+		double s = 0.;
+		for (int i = 0; i < RED_BLOCKS / 64; ++i) s += red[i][threadIdx.x];
+		cnt->macro[threadIdx.x] += s;
+	}
 }
 
-void launch_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, hipStream_t s) {
+void launch_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, double* stage, hipStream_t s) {
 	if (nblocks == 0) return;
-	hipLaunchKernelGGL(k_force_reduce, dim3(1), dim3(256), 0, s, cnt, partials, nblocks);
+	hipLaunchKernelGGL(k_force_reduce1, dim3(RED_BLOCKS), dim3(256), 0, s, partials, nblocks, stage);
+	hipLaunchKernelGGL(k_force_reduce2, dim3(1), dim3(RED_BLOCKS), 0, s, cnt, stage);
 }
 
 __global__ void k_clear_macro(DevCounters* cnt) {

@@ -18,6 +18,31 @@ constexpr int TPB = 256;
 __device__ __forceinline__ double next_toward_up(double x) { return nextafter(x, x + 1.0); }
 __device__ __forceinline__ double next_toward_down(double x) { return nextafter(x, x - 1.0); }
 
+// One atomic per RUN of equal keys inside a wave instead of one per molecule: the input is (nearly) cell-sorted from
+// the previous step, so a wave of 64 molecules touches ~5 cells.  Must be called by converged code paths only for
+// the lanes that take part (others pass through the ballot as inactive).
+__device__ __forceinline__ uint32_t cell_counter_add(uint32_t* count, uint32_t key) {
+	const unsigned long long act = __ballot(1);
+	const int lane = threadIdx.x & 63;
+	const uint32_t prev = __shfl_up(key, 1);
+	const bool prev_active = lane > 0 && ((act >> (lane - 1)) & 1ull);
+	const bool head = !prev_active || prev != key;
+	const unsigned long long heads = __ballot(head);
+	// run of this lane: [start, end) in lane numbers, all active lanes in it are contiguous and share `key`
+	const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+	const int start = 63 - __clzll(below);
+	const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1));
+	const unsigned long long act_above = (lane == 63) ? 0ull : (~act >> (lane + 1));
+	int len_after = 63 - lane;  // lanes after me up to the wave end
+	if (above) len_after = min(len_after, __ffsll((long long)above) - 1);
+	if (act_above) len_after = min(len_after, __ffsll((long long)act_above) - 1);
+	const int end = lane + 1 + len_after;
+	uint32_t base = 0;
+	if (head) base = atomicAdd(&count[key], (uint32_t)(end - start));
+	base = __shfl(base, start);
+	return base + (uint32_t)(lane - start);
+}
+
 // ---- stage A: wrap / classify / key / in-cell rank --------------------------------------------------------------
 __global__ void __launch_bounds__(TPB) k_classify(RebinArgs a) {
 	const uint32_t p = blockIdx.x * TPB + threadIdx.x;
@@ -97,7 +122,7 @@ __global__ void __launch_bounds__(TPB) k_classify(RebinArgs a) {
 	const int cz = cell_coord_owned(a.g, 2, r[2]);
 	key = (uint32_t)cell_index(a.g, cx, cy, cz);
 	a.key[p] = key;
-	a.rank[p] = atomicAdd(&a.count[key], 1u);
+	a.rank[p] = cell_counter_add(a.count, key);
 }
 
 // ---- exclusive scan over the cell grid, restricted to one cell class --------------------------------------------
@@ -199,12 +224,14 @@ static void run_scan(const Grid& g, const uint32_t* count, uint32_t* blocksum, u
 
 // ---- stage B: scatter -> canonical in-cell order -> gather ------------------------------------------------------
 __global__ void __launch_bounds__(TPB) k_scatter(const uint32_t* key, const uint32_t* rank, const uint32_t* cell_begin,
-												 uint32_t* perm, uint32_t n, uint32_t sub) {
+												 uint32_t* perm, const uint64_t* id, uint64_t* idk, uint32_t n, uint32_t sub) {
 	const uint32_t p = blockIdx.x * TPB + threadIdx.x;
 	if (p >= n) return;
 	const uint32_t k = key[p];
 	if (k == KEY_INVALID) return;
-	perm[cell_begin[k] + rank[p] - sub] = p;
+	const uint32_t slot = cell_begin[k] + rank[p] - sub;
+	perm[slot] = p;
+	if (idk) idk[slot] = id[p];  // ids in slot order: the canonical-order pass reads them contiguously per cell
 }
 
 // one thread per cell: insertion sort of the cell's slice of `perm` by molecule id (cells hold ~12 molecules)
@@ -231,10 +258,25 @@ __global__ void __launch_bounds__(TPB) k_cellsort(Grid g, const uint32_t* cell_b
 	}
 }
 
+// Gather into the new set.  Slot k (arrival order inside its cell) is moved to its canonical position: the cell's
+// molecules ordered by id, found by counting the smaller ids in the cell's slice (a dozen contiguous, L1-resident
+// u64) — no serial per-cell sort, every thread stays busy.
 __global__ void __launch_bounds__(TPB) k_gather(RebinArgs a) {
-	const uint32_t p = blockIdx.x * TPB + threadIdx.x;
-	if (p >= a.cnt->n_real) return;
-	const uint32_t i = a.perm[p];
+	const uint32_t k = blockIdx.x * TPB + threadIdx.x;
+	if (k >= a.cnt->n_real) return;
+	const uint32_t i = a.perm[k];
+	const uint32_t key = a.key[i];
+	uint32_t p = k;
+	if (a.deterministic) {
+		const uint32_t cb = a.cell_begin[key], ce = a.cell_end[key];
+		const uint64_t myid = a.idk[k];
+		uint32_t r = 0;
+		for (uint32_t q = cb; q < ce; ++q) {
+			const uint64_t o = a.idk[q];
+			r += (o < myid) || (o == myid && q < k);
+		}
+		p = cb + r;
+	}
 	a.dst.x[p] = a.src.x[i];
 	a.dst.y[p] = a.src.y[i];
 	a.dst.z[p] = a.src.z[i];
@@ -243,7 +285,7 @@ __global__ void __launch_bounds__(TPB) k_gather(RebinArgs a) {
 	a.dst.vz[p] = a.src.vz[i];
 	a.dst.id[p] = a.src.id[i];
 	a.dst.cid[p] = a.src.cid[i];
-	a.ckey[p] = a.key[i];
+	a.ckey[p] = key;
 	if (a.has_rot) {
 		a.dst.q0[p] = a.src.q0[i];
 		a.dst.q1[p] = a.src.q1[i];
@@ -266,10 +308,8 @@ void launch_rebin_sort_gather(const RebinArgs& a, hipStream_t s) {
 	run_scan(a.g, a.count, a.blocksum, a.cell_begin, a.cell_end, a.cnt, 0, s);
 	if (a.n_in == 0) return;
 	const dim3 grid((a.n_in + TPB - 1) / TPB);
-	hipLaunchKernelGGL(k_scatter, grid, dim3(TPB), 0, s, a.key, a.rank, a.cell_begin, a.perm, a.n_in, 0u);
-	if (a.deterministic)
-		hipLaunchKernelGGL(k_cellsort, dim3((a.g.ncells + TPB - 1) / TPB), dim3(TPB), 0, s, a.g, a.cell_begin, a.cell_end,
-						   a.perm, a.src.id, a.cnt, 0);
+	hipLaunchKernelGGL(k_scatter, grid, dim3(TPB), 0, s, a.key, a.rank, a.cell_begin, a.perm, a.src.id,
+					   a.deterministic ? a.idk : nullptr, a.n_in, 0u);
 	hipLaunchKernelGGL(k_gather, grid, dim3(TPB), 0, s, a);
 }
 
@@ -302,7 +342,7 @@ __global__ void __launch_bounds__(TPB) k_leave_import(RebinArgs a, const double*
 	const int cz = cell_coord_owned(a.g, 2, r[4]);
 	const uint32_t key = (uint32_t)cell_index(a.g, cx, cy, cz);
 	a.key[p] = key;
-	a.rank[p] = atomicAdd(&a.count[key], 1u);
+	a.rank[p] = cell_counter_add(a.count, key);
 }
 
 void launch_leave_import(const RebinArgs& a, const double* dev_records, uint32_t n, uint32_t at, hipStream_t s) {
@@ -348,15 +388,47 @@ __device__ __forceinline__ void halo_stage_write(const HaloArgs& a, uint32_t slo
 
 __global__ void __launch_bounds__(TPB) k_halo_gen(HaloArgs a) {
 	const uint32_t p = blockIdx.x * TPB + threadIdx.x;
-	if (p >= a.cnt->n_real) return;
-	const double r[3] = {a.mol.x[p], a.mol.y[p], a.mol.z[p]};
+	const bool valid = p < a.cnt->n_real;
+	double r[3] = {0., 0., 0.};
+	if (valid) {
+		r[0] = a.mol.x[p];
+		r[1] = a.mol.y[p];
+		r[2] = a.mol.z[p];
+	}
 	bool lo[3], hi[3];
 	bool any = false;
 	for (int d = 0; d < 3; ++d) {
-		lo[d] = r[d] < a.g.bmin[d] + a.rc;   // region [min, min+rc): DomainDecompBase.cpp:309-311
-		hi[d] = r[d] >= a.g.bmax[d] - a.rc;  // region [max-rc, max):  DomainDecompBase.cpp:312-315
+		lo[d] = valid && r[d] < a.g.bmin[d] + a.rc;   // region [min, min+rc): DomainDecompBase.cpp:309-311
+		hi[d] = valid && r[d] >= a.g.bmax[d] - a.rc;  // region [max-rc, max):  DomainDecompBase.cpp:312-315
 		any |= lo[d] | hi[d];
 	}
+	// local images of the whole wave get their staging slots from ONE atomic (a single global counter would
+	// otherwise serialise every boundary molecule of the domain)
+	uint32_t nloc = 0;
+	if (any) {
+		for (int sz = -1; sz <= 1; ++sz) {
+			if (!(sz == 0 || (sz < 0 ? lo[2] : hi[2]))) continue;
+			for (int sy = -1; sy <= 1; ++sy) {
+				if (!(sy == 0 || (sy < 0 ? lo[1] : hi[1]))) continue;
+				for (int sx = -1; sx <= 1; ++sx) {
+					if (!(sx == 0 || (sx < 0 ? lo[0] : hi[0]))) continue;
+					if (sx == 0 && sy == 0 && sz == 0) continue;
+					nloc += (a.nbr[(sz + 1) * 9 + (sy + 1) * 3 + (sx + 1)] == a.my_rank) ? 1u : 0u;
+				}
+			}
+		}
+	}
+	uint32_t incl = nloc;
+	const int lane = threadIdx.x & 63;
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t t = __shfl_up(incl, o);
+		if (lane >= o) incl += t;
+	}
+	const uint32_t wave_total = __shfl(incl, 63);
+	uint32_t wave_base = 0;
+	if (lane == 63 && wave_total) wave_base = atomicAdd(&a.cnt->n_halo_staged, wave_total);
+	wave_base = __shfl(wave_base, 63);
+	uint32_t my_slot = wave_base + incl - nloc;
 	if (!any) return;
 	const uint64_t id = a.mol.id[p];
 	const int32_t cid = a.mol.cid[p];
@@ -389,7 +461,7 @@ __global__ void __launch_bounds__(TPB) k_halo_gen(HaloArgs a) {
 							if (rn[d] < a.g.bmax[d]) rn[d] = next_toward_up(a.g.bmax[d]);
 						}
 					}
-					const uint32_t slot = atomicAdd(&a.cnt->n_halo_staged, 1u);
+					const uint32_t slot = my_slot++;
 					if (slot >= a.cap_halo) {
 						atomicAdd(&a.cnt->err_overflow, 1u);
 						continue;

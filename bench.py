@@ -148,6 +148,10 @@ def main():
     import torch
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)")
+    # rehearsal mode: several ranks on ONE GPU with a gloo transport staged through the host (RCCL needs a GPU per rank)
+    rehearse = os.environ.get("LS1_BENCH_BACKEND", "nccl") == "gloo"
+    if rehearse:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
 
     inp = importlib.import_module("ls1-mardyn_amd.inp")
@@ -155,10 +159,13 @@ def main():
     n = args.n_per_dim
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         decomp = importlib.import_module("ls1-mardyn_amd.decomp")
         sim = decomp.build_weak_scaling_box(comps, RC, n, world, rank, local_rank, bcc_box, cic=args.cic or None,
-                                            kernel=args.kernel)
+                                            kernel=args.kernel, stage_through_host=rehearse)
         n_total = sim.n_global
     else:
         engine_mod = importlib.import_module("ls1-mardyn_amd.engine")
@@ -200,7 +207,7 @@ def main():
     e.timing_enable(False)
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

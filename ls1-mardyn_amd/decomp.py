@@ -101,8 +101,11 @@ class CartesianDecomposition:
 class HaloExchanger:
     """Per-peer merged exchange of packed records (leaving molecules or halo copies)."""
 
-    def __init__(self, decomp: CartesianDecomposition, engine, dist, device, group=None):
+    def __init__(self, decomp: CartesianDecomposition, engine, dist, device, group=None, stage_through_host=False):
         self.dc, self.engine, self.dist, self.device, self.group = decomp, engine, dist, device, group
+        # stage_through_host: the engine works on `device` buffers but the process group moves CPU tensors (gloo);
+        # used to rehearse the multi-process path when several ranks share one GPU (RCCL needs one GPU per rank)
+        self.stage = bool(stage_through_host)
         self.nbr = decomp.neighbor_table()
         self.peers = decomp.peers()
         # directions of every rank that point at me, per source rank (to size the receive)
@@ -123,7 +126,7 @@ class HaloExchanger:
         w = RECORD_DOUBLES[kind]
         counts = self.engine.export_counts(kind).astype(np.int64)  # [27]
         if self.peers:
-            mine = torch.from_numpy(counts).to(self.device)
+            mine = torch.from_numpy(counts).to("cpu" if self.stage else self.device)
             lst = [torch.empty_like(mine) for _ in range(self.dc.world)]
             dist.all_gather(lst, mine, group=self.group)
             allc = torch.stack(lst).cpu().numpy()
@@ -139,10 +142,13 @@ class HaloExchanger:
                     if c:
                         self.engine.export_pack(kind, d, self._ptr(buf) + off * w * 8, c)
                         off += c
+                if self.stage:
+                    torch.cuda.synchronize()
+                    buf = buf.cpu()
                 send_keep.append(buf)
                 ops.append(dist.P2POp(dist.isend, buf, p, group=self.group))
             if n_in:
-                rb = torch.empty(n_in * w, dtype=torch.float64, device=self.device)
+                rb = torch.empty(n_in * w, dtype=torch.float64, device="cpu" if self.stage else self.device)
                 recv_bufs.append((rb, n_in))
                 ops.append(dist.P2POp(dist.irecv, rb, p, group=self.group))
         reqs = dist.batch_isend_irecv(ops) if ops else []
@@ -153,6 +159,8 @@ class HaloExchanger:
         if self.device.type == "cuda":
             torch.cuda.current_stream().synchronize()
         for rb, n_in in recv_bufs:
+            if self.stage:
+                rb = rb.to(self.device)
             self.engine.import_records(kind, self._ptr(rb), n_in)
         self.engine.import_done(kind)
 
@@ -161,9 +169,10 @@ class DistributedSimulation:
     """One rank of the decomposed time loop (the overlapped variant of Simulation::simulate,
     Simulation.cpp:1015-1019,1301-1319 -> NonBlockingMPIMultiStepHandler::performOverlappingTasks)."""
 
-    def __init__(self, decomp: CartesianDecomposition, engine, dist, device, group=None):
+    def __init__(self, decomp: CartesianDecomposition, engine, dist, device, group=None, stage_through_host=False):
         self.dc, self.engine, self.dist, self.device, self.group = decomp, engine, dist, device, group
-        self.ex = HaloExchanger(decomp, engine, dist, device, group)
+        self.stage = bool(stage_through_host)
+        self.ex = HaloExchanger(decomp, engine, dist, device, group, stage_through_host)
         self.grid_desc = decomp.describe()
         self.n_global = None
         self._torch = __import__("torch")
@@ -201,14 +210,15 @@ class DistributedSimulation:
         """Domain::calculateGlobalValues: one all_reduce of {U_pot, virial, sum mv^2, sum Iw^2, N, rotDOF}."""
         torch = self._torch
         t = torch.tensor([macro[0], macro[1], kin[0], kin[1], float(kin[2]), float(kin[3])], dtype=torch.float64,
-                         device=self.device)
+                         device="cpu" if self.stage else self.device)
         self.dist.all_reduce(t, group=self.group)
         v = t.cpu().numpy()
         return dict(upot=float(v[0]), virial=float(v[1]), summv2=float(v[2]), sumIw2=float(v[3]), n=int(v[4]),
                     rot_dof=int(v[5]))
 
 
-def build_weak_scaling_box(comps, rc, n_per_dim, world, rank, local_rank, bcc_box, cic=None, kernel=0):
+def build_weak_scaling_box(comps, rc, n_per_dim, world, rank, local_rank, bcc_box, cic=None, kernel=0,
+                           stage_through_host=False):
     """bench.py helper: every rank owns a 2*n^3 jittered bcc block; the global box is the rank grid of such blocks."""
     import torch
     import torch.distributed as dist
@@ -232,7 +242,7 @@ def build_weak_scaling_box(comps, rc, n_per_dim, world, rank, local_rank, bcc_bo
     n = len(r)
     ids = np.arange(1, n + 1, dtype=np.uint64) + np.uint64(rank) * np.uint64(n)
     eng.upload(ids, np.zeros(n, np.int32), r, v)
-    sim = DistributedSimulation(dc, eng, dist, torch.device("cuda", local_rank))
+    sim = DistributedSimulation(dc, eng, dist, torch.device("cuda", local_rank), stage_through_host=stage_through_host)
     sim.n_global = n * world
     sim.initial_forces()
     return sim

@@ -216,6 +216,17 @@ def main():
     rebin_ms, _ = e.timing("rebin")
     halo_ms, _ = e.timing("halo")
     n_local = e.count()[0]
+    # HBM traffic of the force kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction, WRITE_SIZE), taken
+    # offline on this exact workload and committed under profiles/ (PMC collection cannot run inside the timed loop)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_b_pmc_summary.json")) as fh:
+            pm = json.load(fh)["force_kernel"]
+        if world == 1 and abs(pm["algorithmic_bytes_per_launch"] - FORCE_BYTES_PER_MOLECULE * n_local) < 1 and \
+                e.get_option("cells_in_cutoff") == 1 and e.get_option("force_kernel") in (0, 2):
+            traffic = pm["traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
     if rank == 0:
         avg_force_s = force_ms / 1e3 / max(force_n, 1)
         achieved = FORCE_BYTES_PER_MOLECULE * n_local / avg_force_s / 1e9
@@ -230,7 +241,7 @@ def main():
                        "molecules_per_gpu": n_local, "decomposition": getattr(sim, "grid_desc", "single GPU, periodic images local"),
                        "force_kernel": e.get_option("force_kernel"), "cells_in_cutoff": e.get_option("cells_in_cutoff")},
             "roofline": {"bound": "hbm", "kernel": "pair-force traversal (k_force_*)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_force_s * 1e3, "launches": int(force_n),
                          "algorithmic_bytes_per_launch": FORCE_BYTES_PER_MOLECULE * n_local,
                          "full_step_frac": STEP_BYTES_PER_MOLECULE * n_total / world * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},

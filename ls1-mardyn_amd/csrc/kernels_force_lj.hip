@@ -231,7 +231,8 @@ __global__ void __launch_bounds__(LTPB, 2) k_force_lj_brick(ForceParams P, int n
 				// issued before the current trip is processed (register double buffer) so LDS latency overlaps the
 				// distance arithmetic; the append is branch-free (misses / overflow write to a per-lane dummy slot).
 				constexpr int U = 4;
-				const uint32_t lbase = (uint32_t)tid;
+				const uint32_t lane_off = (uint32_t)tid * 2u;  // byte offset of this lane inside a list row
+				char* const lst_bytes = reinterpret_cast<char*>(lst);
 #pragma unroll
 				for (int dz = -HW; dz <= HW; ++dz) {
 #pragma unroll
@@ -260,7 +261,7 @@ __global__ void __launch_bounds__(LTPB, 2) k_force_lj_brick(ForceParams P, int n
 								bool hit = (r2 < rc2) & ((uint32_t)u < nvalid);
 								if (dz == 0 && dy == 0) hit &= (j0 + u != ii);  // self lives in the own row only
 								const uint32_t slot = min(hit ? cnt : (uint32_t)CAPL, (uint32_t)CAPL);
-								lst[slot * LTPB + lbase] = (uint16_t)(j0 + u);
+								*reinterpret_cast<uint16_t*>(lst_bytes + ((slot << 9) | lane_off)) = (uint16_t)(j0 + u);
 								cnt += hit ? 1u : 0u;
 							}
 #pragma unroll
@@ -279,7 +280,7 @@ __global__ void __launch_bounds__(LTPB, 2) k_force_lj_brick(ForceParams P, int n
 					for (; s2 + 4 <= cnt; s2 += 4) {
 						uint32_t jj[4];
 #pragma unroll
-						for (int u = 0; u < 4; ++u) jj[u] = lst[(s2 + u) * LTPB + lbase];
+						for (int u = 0; u < 4; ++u) jj[u] = *reinterpret_cast<uint16_t*>(lst_bytes + (((s2 + u) << 9) | lane_off));
 						double px[4], py[4], pz[4];
 #pragma unroll
 						for (int u = 0; u < 4; ++u) {
@@ -291,7 +292,7 @@ __global__ void __launch_bounds__(LTPB, 2) k_force_lj_brick(ForceParams P, int n
 						for (int u = 0; u < 4; ++u) lj_pair_in(xi, yi, zi, px[u], py[u], pz[u], eps24, sig2, acc, slj);
 					}
 					for (; s2 < cnt; ++s2) {
-						const uint32_t j = lst[s2 * LTPB + lbase];
+						const uint32_t j = *reinterpret_cast<uint16_t*>(lst_bytes + ((s2 << 9) | lane_off));
 						lj_pair_in(xi, yi, zi, sx[j], sy[j], sz[j], eps24, sig2, acc, slj);
 					}
 					acc.u6 = fma(eps24, slj, shift6 * (double)cnt);

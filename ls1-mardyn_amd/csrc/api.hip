@@ -752,9 +752,18 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 	HIPCHK(c, hipSetDevice(c->device));
 	for (unsigned long s = 0; s < nsteps; ++s) {
 		int rc;
-		if ((rc = ls1hip_kick_drift(c, dt)) || (rc = ls1hip_rebin(c)) || (rc = ls1hip_halo(c)) ||
-			(rc = ls1hip_forces(c, 0, nullptr, nullptr)) || (rc = ls1hip_kick(c, 0.5 * dt, nullptr, nullptr, nullptr, nullptr)))
-			return rc;
+		if (s == 0) {
+			if ((rc = ls1hip_kick_drift(c, dt))) return rc;
+		} else {
+			// post-force kick of step s-1 fused with the pre-force kick+drift of step s (same F, one pass)
+			TimedScope ts(c, c->t_integrate);
+			launch_kick_then_kick_drift(integ_args(c, dt), c->stream);
+			c->binned = false;
+			c->halo_valid = false;
+			c->forces_valid = false;
+		}
+		if ((rc = ls1hip_rebin(c)) || (rc = ls1hip_halo(c)) || (rc = ls1hip_forces(c, 0, nullptr, nullptr))) return rc;
+		if (s + 1 == nsteps && (rc = ls1hip_kick(c, 0.5 * dt, nullptr, nullptr, nullptr, nullptr))) return rc;
 	}
 	int rc = sync_counters(c);
 	if (rc) return rc;

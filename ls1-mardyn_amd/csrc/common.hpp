@@ -188,6 +188,7 @@ struct IntegArgs {
 };
 void launch_kick_drift(const IntegArgs& a, hipStream_t s);
 void launch_kick(const IntegArgs& a, hipStream_t s, uint32_t* nblocks);
+void launch_kick_then_kick_drift(const IntegArgs& a, hipStream_t s);
 void launch_kin_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, hipStream_t s);
 
 }  // namespace ls1

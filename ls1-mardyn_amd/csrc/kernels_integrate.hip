@@ -62,6 +62,67 @@ __global__ void __launch_bounds__(ITPB) k_kick_drift(IntegArgs a) {
 	}
 }
 
+// Inside ls1hip_run two consecutive Leapfrog events touch the same arrays back to back: upd_postF of step n
+// (v += dt/2m F, L += dt/2 M) and upd_preF of step n+1 (v += dt/2m F; r += dt v; quaternion/L half steps with the SAME
+// F, M).  Fused: v is read and written once, F read once (saves 72 B per molecule per step).  The arithmetic is the
+// unfused sequence, operation for operation, so trajectories are bitwise identical to the piecewise calls.
+template <bool HAS_ROT>
+__global__ void __launch_bounds__(ITPB) k_kick_then_kick_drift(IntegArgs a) {
+	const uint32_t p = blockIdx.x * ITPB + threadIdx.x;
+	if (p >= a.cnt->n_real) return;
+	const double dt = a.dt, dt_halve = .5 * dt;
+	const int c = HAS_ROT ? a.mol.cid[p] : (a.ct->ncomp > 1 ? a.mol.cid[p] : 0);
+	const double dtInv2m = dt_halve / a.ct->mass[c];
+	const double Fx = a.frc.Fx[p], Fy = a.frc.Fy[p], Fz = a.frc.Fz[p];
+	double vx = a.mol.vx[p] + dtInv2m * Fx;  // upd_postF
+	double vy = a.mol.vy[p] + dtInv2m * Fy;
+	double vz = a.mol.vz[p] + dtInv2m * Fz;
+	vx += dtInv2m * Fx;  // upd_preF
+	vy += dtInv2m * Fy;
+	vz += dtInv2m * Fz;
+	a.mol.vx[p] = vx;
+	a.mol.vy[p] = vy;
+	a.mol.vz[p] = vz;
+	a.mol.x[p] += dt * vx;
+	a.mol.y[p] += dt * vy;
+	a.mol.z[p] += dt * vz;
+	if (HAS_ROT) {
+		double q[4] = {a.mol.q0[p], a.mol.q1[p], a.mol.q2[p], a.mol.q3[p]};
+		const double Mx = a.frc.Mx[p], My = a.frc.My[p], Mz = a.frc.Mz[p];
+		V3 D = {a.mol.Dx[p] + dt_halve * Mx, a.mol.Dy[p] + dt_halve * My, a.mol.Dz[p] + dt_halve * Mz};  // upd_postF
+		const V3 invI = {a.ct->invI[c][0], a.ct->invI[c][1], a.ct->invI[c][2]};
+		V3 w = rotate_inv(rot_of(q[0], q[1], q[2], q[3]), D);
+		w = {w.x * invI.x, w.y * invI.y, w.z * invI.z};
+		double dq[4], qh[4];
+		q_diff(q, w, dq);
+		for (int k = 0; k < 4; ++k) qh[k] = dq[k] * dt_halve + q[k];
+		double qcorr = 1. / sqrt(qh[0] * qh[0] + qh[1] * qh[1] + qh[2] * qh[2] + qh[3] * qh[3]);
+		for (int k = 0; k < 4; ++k) qh[k] *= qcorr;
+		D.x += dt_halve * Mx;
+		D.y += dt_halve * My;
+		D.z += dt_halve * Mz;
+		w = rotate_inv(rot_of(qh[0], qh[1], qh[2], qh[3]), D);
+		w = {w.x * invI.x, w.y * invI.y, w.z * invI.z};
+		q_diff(qh, w, dq);
+		for (int k = 0; k < 4; ++k) q[k] += dq[k] * dt;
+		qcorr = 1. / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+		a.mol.q0[p] = q[0] * qcorr;
+		a.mol.q1[p] = q[1] * qcorr;
+		a.mol.q2[p] = q[2] * qcorr;
+		a.mol.q3[p] = q[3] * qcorr;
+		a.mol.Dx[p] = D.x;
+		a.mol.Dy[p] = D.y;
+		a.mol.Dz[p] = D.z;
+	}
+}
+
+void launch_kick_then_kick_drift(const IntegArgs& a, hipStream_t s) {
+	if (a.n_cap == 0) return;
+	const dim3 grid((a.n_cap + ITPB - 1) / ITPB);
+	if (a.has_rot) hipLaunchKernelGGL(k_kick_then_kick_drift<true>, grid, dim3(ITPB), 0, s, a);
+	else hipLaunchKernelGGL(k_kick_then_kick_drift<false>, grid, dim3(ITPB), 0, s, a);
+}
+
 __device__ __forceinline__ double wave_sum_i(double v) {
 	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
 	return v;

@@ -386,50 +386,36 @@ __device__ __forceinline__ void halo_stage_write(const HaloArgs& a, uint32_t slo
 	a.hs.key[slot] = key;
 }
 
-__global__ void __launch_bounds__(TPB) k_halo_gen(HaloArgs a) {
-	const uint32_t p = blockIdx.x * TPB + threadIdx.x;
-	const bool valid = p < a.cnt->n_real;
-	double r[3] = {0., 0., 0.};
-	if (valid) {
-		r[0] = a.mol.x[p];
-		r[1] = a.mol.y[p];
-		r[2] = a.mol.z[p];
-	}
-	bool lo[3], hi[3];
-	bool any = false;
-	for (int d = 0; d < 3; ++d) {
-		lo[d] = valid && r[d] < a.g.bmin[d] + a.rc;   // region [min, min+rc): DomainDecompBase.cpp:309-311
-		hi[d] = valid && r[d] >= a.g.bmax[d] - a.rc;  // region [max-rc, max):  DomainDecompBase.cpp:312-315
-		any |= lo[d] | hi[d];
-	}
-	// local images of the whole wave get their staging slots from ONE atomic (a single global counter would
-	// otherwise serialise every boundary molecule of the domain)
+// number of local periodic images of a molecule with near-face flags lo/hi
+__device__ __forceinline__ uint32_t halo_count_local(const HaloArgs& a, const bool lo[3], const bool hi[3]) {
 	uint32_t nloc = 0;
-	if (any) {
-		for (int sz = -1; sz <= 1; ++sz) {
-			if (!(sz == 0 || (sz < 0 ? lo[2] : hi[2]))) continue;
-			for (int sy = -1; sy <= 1; ++sy) {
-				if (!(sy == 0 || (sy < 0 ? lo[1] : hi[1]))) continue;
-				for (int sx = -1; sx <= 1; ++sx) {
-					if (!(sx == 0 || (sx < 0 ? lo[0] : hi[0]))) continue;
-					if (sx == 0 && sy == 0 && sz == 0) continue;
-					nloc += (a.nbr[(sz + 1) * 9 + (sy + 1) * 3 + (sx + 1)] == a.my_rank) ? 1u : 0u;
-				}
+	for (int sz = -1; sz <= 1; ++sz) {
+		if (!(sz == 0 || (sz < 0 ? lo[2] : hi[2]))) continue;
+		for (int sy = -1; sy <= 1; ++sy) {
+			if (!(sy == 0 || (sy < 0 ? lo[1] : hi[1]))) continue;
+			for (int sx = -1; sx <= 1; ++sx) {
+				if (!(sx == 0 || (sx < 0 ? lo[0] : hi[0]))) continue;
+				if (sx == 0 && sy == 0 && sz == 0) continue;
+				nloc += (a.nbr[(sz + 1) * 9 + (sy + 1) * 3 + (sx + 1)] == a.my_rank) ? 1u : 0u;
 			}
 		}
 	}
-	uint32_t incl = nloc;
-	const int lane = threadIdx.x & 63;
-	for (int o = 1; o < 64; o <<= 1) {
-		const uint32_t t = __shfl_up(incl, o);
-		if (lane >= o) incl += t;
+	return nloc;
+}
+
+__device__ __forceinline__ bool halo_flags(const HaloArgs& a, const double r[3], bool lo[3], bool hi[3]) {
+	bool any = false;
+	for (int d = 0; d < 3; ++d) {
+		lo[d] = r[d] < a.g.bmin[d] + a.rc;   // region [min, min+rc): DomainDecompBase.cpp:309-311
+		hi[d] = r[d] >= a.g.bmax[d] - a.rc;  // region [max-rc, max):  DomainDecompBase.cpp:312-315
+		any |= lo[d] | hi[d];
 	}
-	const uint32_t wave_total = __shfl(incl, 63);
-	uint32_t wave_base = 0;
-	if (lane == 63 && wave_total) wave_base = atomicAdd(&a.cnt->n_halo_staged, wave_total);
-	wave_base = __shfl(wave_base, 63);
-	uint32_t my_slot = wave_base + incl - nloc;
-	if (!any) return;
+	return any;
+}
+
+// emit all images of molecule p; local images go to staging slots my_slot, my_slot+1, ...
+__device__ __forceinline__ void halo_emit(const HaloArgs& a, uint32_t p, const double r[3], const bool lo[3],
+										  const bool hi[3], uint32_t& my_slot) {
 	const uint64_t id = a.mol.id[p];
 	const int32_t cid = a.mol.cid[p];
 	double q0 = 1., q1 = 0., q2 = 0., q3 = 0.;
@@ -490,6 +476,49 @@ __global__ void __launch_bounds__(TPB) k_halo_gen(HaloArgs a) {
 	}
 }
 
+// One lane per CELL of the grid; only cells of the outermost hw layers of owned cells can hold molecules within rc of
+// a face (cell edge >= rc/hw), all other lanes leave at once, so the pass reads ~6 % of the molecules instead of all.
+// Local images of the whole wave get their staging slots from ONE atomic (a single global counter would otherwise
+// serialise every boundary molecule of the domain).
+__global__ void __launch_bounds__(TPB) k_halo_gen(HaloArgs a) {
+	const int c = blockIdx.x * TPB + threadIdx.x;
+	uint32_t pb = 0, pe = 0;
+	if (c < a.g.ncells) {
+		int cx, cy, cz;
+		cell_coords(a.g, c, cx, cy, cz);
+		const int hw = a.g.hw;
+		const bool owned = !cell_is_halo(a.g, cx, cy, cz);
+		const bool shell = cx < 2 * hw || cy < 2 * hw || cz < 2 * hw || cx >= a.g.dims[0] - 2 * hw ||
+						   cy >= a.g.dims[1] - 2 * hw || cz >= a.g.dims[2] - 2 * hw;
+		if (owned && shell) {
+			pb = a.cell_begin[c];
+			pe = a.cell_end[c];
+		}
+	}
+	uint32_t nloc = 0;
+	for (uint32_t p = pb; p < pe; ++p) {
+		const double r[3] = {a.mol.x[p], a.mol.y[p], a.mol.z[p]};
+		bool lo[3], hi[3];
+		if (halo_flags(a, r, lo, hi)) nloc += halo_count_local(a, lo, hi);
+	}
+	uint32_t incl = nloc;
+	const int lane = threadIdx.x & 63;
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t t = __shfl_up(incl, o);
+		if (lane >= o) incl += t;
+	}
+	const uint32_t wave_total = __shfl(incl, 63);
+	uint32_t wave_base = 0;
+	if (lane == 63 && wave_total) wave_base = atomicAdd(&a.cnt->n_halo_staged, wave_total);
+	wave_base = __shfl(wave_base, 63);
+	uint32_t my_slot = wave_base + incl - nloc;
+	for (uint32_t p = pb; p < pe; ++p) {
+		const double r[3] = {a.mol.x[p], a.mol.y[p], a.mol.z[p]};
+		bool lo[3], hi[3];
+		if (halo_flags(a, r, lo, hi)) halo_emit(a, p, r, lo, hi, my_slot);
+	}
+}
+
 __global__ void __launch_bounds__(TPB) k_halo_import(HaloArgs a, const double* rec, uint32_t n) {
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	if (i >= n) return;
@@ -541,7 +570,7 @@ void launch_halo_generate(const HaloArgs& a, hipStream_t s) {
 	hipLaunchKernelGGL(k_halo_reset, dim3(1), dim3(1), 0, s, a.cnt);
 	hipLaunchKernelGGL(k_zero_halo_counts, dim3((a.g.ncells + TPB - 1) / TPB), dim3(TPB), 0, s, a.g, a.count);
 	if (a.n_real_cap == 0) return;
-	hipLaunchKernelGGL(k_halo_gen, dim3((a.n_real_cap + TPB - 1) / TPB), dim3(TPB), 0, s, a);
+	hipLaunchKernelGGL(k_halo_gen, dim3((a.g.ncells + TPB - 1) / TPB), dim3(TPB), 0, s, a);
 }
 
 void launch_halo_import(const HaloArgs& a, const double* dev_records, uint32_t n, hipStream_t s) {

@@ -103,8 +103,9 @@ static void free_mol(ls1hip_ctx* c) {
 	c->partials_cap = 0;
 }
 static void free_cells(ls1hip_ctx* c) {
-	dfree(c->d_count); dfree(c->d_cell_begin); dfree(c->d_cell_end); dfree(c->d_blocksum);
+	dfree(c->d_count); dfree(c->d_cell_begin); dfree(c->d_cell_end); dfree(c->d_blocksum); dfree(c->d_shell);
 	c->cells_alloc = 0;
+	c->n_shell = 0;
 }
 
 // ---- lifetime ------------------------------------------------------------------------------------------------------
@@ -365,6 +366,23 @@ extern "C" int ls1hip_set_domain(ls1hip_ctx* c, const double global_len[3], cons
 			return rc;
 		c->cells_alloc = nc;
 	}
+	{
+		// owned cells within 2*hw of a face: the only cells whose molecules can lie within rc of the boundary
+		std::vector<uint32_t> shell;
+		const int hw = g.hw;
+		for (int cz = hw; cz < g.dims[2] - hw; ++cz)
+			for (int cy = hw; cy < g.dims[1] - hw; ++cy)
+				for (int cx = hw; cx < g.dims[0] - hw; ++cx)
+					if (cx < 2 * hw || cy < 2 * hw || cz < 2 * hw || cx >= g.dims[0] - 2 * hw || cy >= g.dims[1] - 2 * hw ||
+						cz >= g.dims[2] - 2 * hw)
+						shell.push_back((uint32_t)cell_index(g, cx, cy, cz));
+		dfree(c->d_shell);
+		int rc = dalloc(c, &c->d_shell, shell.size());
+		if (rc) return rc;
+		c->n_shell = (uint32_t)shell.size();
+		if (!shell.empty())
+			HIPCHK(c, hipMemcpy(c->d_shell, shell.data(), shell.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	}
 	HIPCHK(c, hipMemsetAsync(c->d_count, 0, nc * sizeof(uint32_t), c->stream));
 	HIPCHK(c, hipMemsetAsync(c->d_cell_begin, 0, nc * sizeof(uint32_t), c->stream));
 	HIPCHK(c, hipMemsetAsync(c->d_cell_end, 0, nc * sizeof(uint32_t), c->stream));
@@ -586,6 +604,8 @@ static HaloArgs halo_args(ls1hip_ctx* c) {
 	a.has_rot = c->h_ct.has_rot;
 	a.perm = c->d_perm; a.count = c->d_count; a.cell_begin = c->d_cell_begin; a.cell_end = c->d_cell_end;
 	a.blocksum = c->d_blocksum;
+	a.shell = c->d_shell;
+	a.nshell = c->n_shell;
 	a.cnt = c->d_cnt;
 	a.n_real_cap = (uint32_t)c->n_real;
 	a.cap_halo = (uint32_t)c->cap_halo;

@@ -111,6 +111,8 @@ struct ls1hip_ctx {
 	uint64_t* d_idk = nullptr;
 	uint32_t *d_count = nullptr, *d_cell_begin = nullptr, *d_cell_end = nullptr, *d_blocksum = nullptr;
 	size_t cells_alloc = 0;
+	uint32_t* d_shell = nullptr;
+	uint32_t n_shell = 0;
 	ls1::DevCounters* d_cnt = nullptr;
 	ls1::DevCounters* h_cnt = nullptr;  // pinned mirror
 	double* d_partials = nullptr;
@@ -154,6 +156,8 @@ struct HaloArgs {
 	HaloStage hs;
 	bool has_rot;
 	uint32_t *perm, *count, *cell_begin, *cell_end, *blocksum;
+	const uint32_t* shell;  // owned cells within 2*hw of a face (the only ones that can feed the halo)
+	uint32_t nshell;
 	DevCounters* cnt;
 	uint32_t n_real_cap, cap_halo;
 	int nbr[27];

@@ -476,27 +476,23 @@ __device__ __forceinline__ void halo_emit(const HaloArgs& a, uint32_t p, const d
 	}
 }
 
-// One lane per CELL of the grid; only cells of the outermost hw layers of owned cells can hold molecules within rc of
-// a face (cell edge >= rc/hw), all other lanes leave at once, so the pass reads ~6 % of the molecules instead of all.
-// Local images of the whole wave get their staging slots from ONE atomic (a single global counter would otherwise
-// serialise every boundary molecule of the domain).
+// 16 lanes per SHELL cell (4 cells per wave).  Only cells of the outermost hw layers of owned cells can hold molecules
+// within rc of a face (cell edge >= rc/hw); their indices are listed once per domain (ls1hip_set_domain), so the pass
+// reads ~6 % of the molecules instead of all.  Local images of the whole wave get their staging slots from ONE atomic (a single
+// global counter would otherwise serialise every boundary molecule of the domain).
+constexpr int HG_LANES = 16;
 __global__ void __launch_bounds__(TPB) k_halo_gen(HaloArgs a) {
-	const int c = blockIdx.x * TPB + threadIdx.x;
+	const uint32_t k = (blockIdx.x * TPB + threadIdx.x) / HG_LANES;  // index into the precomputed shell-cell list
+	const uint32_t sub = threadIdx.x % HG_LANES;
 	uint32_t pb = 0, pe = 0;
-	if (c < a.g.ncells) {
-		int cx, cy, cz;
-		cell_coords(a.g, c, cx, cy, cz);
-		const int hw = a.g.hw;
-		const bool owned = !cell_is_halo(a.g, cx, cy, cz);
-		const bool shell = cx < 2 * hw || cy < 2 * hw || cz < 2 * hw || cx >= a.g.dims[0] - 2 * hw ||
-						   cy >= a.g.dims[1] - 2 * hw || cz >= a.g.dims[2] - 2 * hw;
-		if (owned && shell) {
-			pb = a.cell_begin[c];
-			pe = a.cell_end[c];
-		}
+	if (k < a.nshell) {
+		const uint32_t c = a.shell[k];
+		pb = a.cell_begin[c];
+		pe = a.cell_end[c];
 	}
+	if (!__any(pe > pb)) return;  // wave-uniform
 	uint32_t nloc = 0;
-	for (uint32_t p = pb; p < pe; ++p) {
+	for (uint32_t p = pb + sub; p < pe; p += HG_LANES) {
 		const double r[3] = {a.mol.x[p], a.mol.y[p], a.mol.z[p]};
 		bool lo[3], hi[3];
 		if (halo_flags(a, r, lo, hi)) nloc += halo_count_local(a, lo, hi);
@@ -512,7 +508,7 @@ __global__ void __launch_bounds__(TPB) k_halo_gen(HaloArgs a) {
 	if (lane == 63 && wave_total) wave_base = atomicAdd(&a.cnt->n_halo_staged, wave_total);
 	wave_base = __shfl(wave_base, 63);
 	uint32_t my_slot = wave_base + incl - nloc;
-	for (uint32_t p = pb; p < pe; ++p) {
+	for (uint32_t p = pb + sub; p < pe; p += HG_LANES) {
 		const double r[3] = {a.mol.x[p], a.mol.y[p], a.mol.z[p]};
 		bool lo[3], hi[3];
 		if (halo_flags(a, r, lo, hi)) halo_emit(a, p, r, lo, hi, my_slot);
@@ -570,7 +566,8 @@ void launch_halo_generate(const HaloArgs& a, hipStream_t s) {
 	hipLaunchKernelGGL(k_halo_reset, dim3(1), dim3(1), 0, s, a.cnt);
 	hipLaunchKernelGGL(k_zero_halo_counts, dim3((a.g.ncells + TPB - 1) / TPB), dim3(TPB), 0, s, a.g, a.count);
 	if (a.n_real_cap == 0) return;
-	hipLaunchKernelGGL(k_halo_gen, dim3((a.g.ncells + TPB - 1) / TPB), dim3(TPB), 0, s, a);
+	if (a.nshell == 0) return;
+	hipLaunchKernelGGL(k_halo_gen, dim3(((size_t)a.nshell * HG_LANES + TPB - 1) / TPB), dim3(TPB), 0, s, a);
 }
 
 void launch_halo_import(const HaloArgs& a, const double* dev_records, uint32_t n, hipStream_t s) {

@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--n-per-dim", type=int, default=171, help="bcc cells per dimension per GPU (N = 2 n^3)")
     ap.add_argument("--kernel", type=int, default=0, help="force kernel variant (LS1HIP_FK_*)")
     ap.add_argument("--cic", type=int, default=0, help="cells in cutoff (0 = engine default)")
+    ap.add_argument("--split", type=int, default=0, help="lanes per molecule in the LDS LJ kernel (0 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -175,6 +176,8 @@ def main():
         if args.cic:
             eng.set_option("cells_in_cutoff", args.cic)
         eng.set_option("force_kernel", args.kernel)
+        if args.split:
+            eng.set_option("lj_split", args.split)
         eng.set_domain([L, L, L])
         N = len(r)
         eng.upload(np.arange(1, N + 1, dtype=np.uint64), np.zeros(N, np.int32), r, v)

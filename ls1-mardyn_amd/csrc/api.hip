@@ -179,6 +179,9 @@ extern "C" int ls1hip_set_option(ls1hip_ctx* c, const char* name, long v) {
 		c->opt_det = v ? 1 : 0;
 	} else if (n == "count_pairs") {
 		c->opt_count_pairs = v ? 1 : 0;
+	} else if (n == "lj_split") {
+		REQUIRE(c, v == 1 || v == 2, "lj_split must be 1 or 2");
+		c->opt_lj_split = v;
 	} else {
 		FAIL(c, LS1HIP_EINVAL, "unknown option '%s'", name);
 	}
@@ -193,6 +196,7 @@ extern "C" int ls1hip_get_option(const ls1hip_ctx* c, const char* name, long* v)
 	else if (n == "compute_vi") *v = c->opt_vi;
 	else if (n == "deterministic") *v = c->opt_det;
 	else if (n == "count_pairs") *v = c->opt_count_pairs;
+	else if (n == "lj_split") *v = c->opt_lj_split;
 	else return LS1HIP_EINVAL;
 	return LS1HIP_OK;
 }
@@ -681,7 +685,7 @@ static int launch_forces(ls1hip_ctx* c, int which) {
 	if (which == 0 || which == 1) launch_clear_macro(c->d_cnt, c->stream);
 	bool done = false;
 	if (c->one_clj && c->opt_force_kernel != LS1HIP_FK_GENERIC && !c->opt_vi && !c->opt_count_pairs) {
-		done = launch_force_lj(P, c->stream, &nblocks, c->d_partials, c->partials_cap);
+		done = launch_force_lj(P, c->stream, &nblocks, c->d_partials, c->partials_cap, (int)c->opt_lj_split);
 	}
 	if (!done) {
 		if (c->opt_force_kernel == LS1HIP_FK_LDS_LIST && !c->one_clj)

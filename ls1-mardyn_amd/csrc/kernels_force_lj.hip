@@ -86,6 +86,7 @@ __device__ __forceinline__ double wave_sum_lj(double v) {
 
 // block-wide exclusive scan of `n` (<= LTPB*4) u32 values held in LDS array v[0..n) -> v becomes exclusive prefix,
 // v[n] = total.  All threads must call.
+template <int NT>
 __device__ __forceinline__ void block_scan_lds(uint32_t* v, int n, uint32_t* wsum) {
 	const int t = threadIdx.x;
 	uint32_t a[4], s = 0;
@@ -111,23 +112,33 @@ __device__ __forceinline__ void block_scan_lds(uint32_t* v, int n, uint32_t* wsu
 		if (i < n) v[i] = ex;
 		ex += a[k];
 	}
-	if (t == LTPB - 1) v[n] = ex;  // last thread's running value = total (its items beyond n contribute 0)
+	if (t == NT - 1) v[n] = ex;  // last thread's running value = total (its items beyond n contribute 0)
 	__syncthreads();
 }
 
-template <int HW, int BX, int BY, int BZ, int CAPJ, int CAPL>
-__global__ void __launch_bounds__(LTPB, 2) k_force_lj_brick(ForceParams P, int nbx, int nby, int nbz) {
+template <int HW, int BX, int BY, int BZ, int CAPJ, int CAPL, int SPLIT>
+__global__ void __launch_bounds__(LTPB * SPLIT, 2 * SPLIT) k_force_lj_brick(ForceParams P, int nbx, int nby, int nbz) {
+	// SPLIT lanes share one molecule: lane `half` scans the neighbour rows half, half+SPLIT, ... (same code, per-lane
+	// row offsets), keeps its own list and partial force; the partial forces are combined with one DPP exchange.
+	// With SPLIT = 2 the workgroup has 512 threads on the same LDS budget (the lists are half as long), i.e. 4
+	// waves per SIMD instead of 2 to hide LDS latency.
+	constexpr int NT = LTPB * SPLIT;
 	constexpr int RX = BX + 2 * HW, RY = BY + 2 * HW, RZ = BZ + 2 * HW;
 	constexpr int NRC = RX * RY * RZ;
 	constexpr int NBC = BX * BY * BZ;
-	static_assert(NRC <= LTPB * 4, "region too large for the block scan");
+	constexpr int NW = 2 * HW + 1;          // cells per neighbour row
+	constexpr int NROWS = NW * NW;          // neighbour rows per molecule
+	constexpr int OWNROW = (NROWS - 1) / 2; // the row that contains the molecule itself
+	constexpr int LSHIFT = (NT == 256) ? 9 : 10;  // log2(bytes per list row)
+	static_assert(NT == 256 || NT == 512, "list addressing assumes 256 or 512 threads");
+	static_assert(NRC <= NT * 4, "region too large for the block scan");
 	__shared__ double sx[CAPJ + 8], sy[CAPJ + 8], sz[CAPJ + 8];  // +8: unrolled reads may run past a row end
-	__shared__ uint16_t lst[(CAPL + 1) * LTPB];  // +1: per-lane dummy slot for branch-free appends
+	__shared__ uint16_t lst[(CAPL + 1) * NT];  // +1: per-lane dummy slot for branch-free appends
 	__shared__ uint32_t cstart[NRC + 1];  // LDS index of the first molecule of every region cell (region-linear order)
 	__shared__ uint32_t gbeg[NRC];        // global index of the first molecule of every region cell
 	__shared__ uint32_t bstart[NBC + 1];  // prefix over the brick's own cells (i-molecule enumeration)
-	__shared__ uint32_t wsum[LTPB / 64];
-	__shared__ double red[LTPB / 64][2];
+	__shared__ uint32_t wsum[NT / 64];
+	__shared__ double red[NT / 64][2];
 
 	const int tid = threadIdx.x;
 	// XCD-aware brick order: workgroups are dealt round-robin to the 8 XCDs, so give every XCD a contiguous run of
@@ -157,7 +168,7 @@ __global__ void __launch_bounds__(LTPB, 2) k_force_lj_brick(ForceParams P, int n
 	}
 
 	// ---- 1. region cell table ------------------------------------------------------------------------------------
-	for (int c = tid; c < NRC; c += LTPB) {
+	for (int c = tid; c < NRC; c += NT) {
 		const int rx = c % RX, ry = (c / RX) % RY, rz = c / (RX * RY);
 		const int gx = x0 - HW + rx, gy = y0 - HW + ry, gz = z0 - HW + rz;
 		uint32_t b = 0, n = 0;
@@ -170,10 +181,10 @@ __global__ void __launch_bounds__(LTPB, 2) k_force_lj_brick(ForceParams P, int n
 		cstart[c] = n;
 	}
 	__syncthreads();
-	block_scan_lds(cstart, NRC, wsum);
+	block_scan_lds<NT>(cstart, NRC, wsum);
 	const uint32_t total = cstart[NRC];
 	// brick cell prefix (own molecules)
-	for (int c = tid; c < NBC; c += LTPB) {
+	for (int c = tid; c < NBC; c += NT) {
 		const int cx = c % BX, cy = (c / BX) % BY, cz = c / (BX * BY);
 		uint32_t n = 0;
 		if (cx < ex && cy < ey && cz < ez) {
@@ -183,13 +194,13 @@ __global__ void __launch_bounds__(LTPB, 2) k_force_lj_brick(ForceParams P, int n
 		bstart[c] = n;
 	}
 	__syncthreads();
-	block_scan_lds(bstart, NBC, wsum);
+	block_scan_lds<NT>(bstart, NBC, wsum);
 	const uint32_t n_i = bstart[NBC];
 	const bool staged = total <= (uint32_t)CAPJ;
 
 	// ---- 2. stage positions (HBM -> LDS, each molecule of the shell read once per brick) ------------------------
 	if (staged) {
-		for (uint32_t s = tid; s < total; s += LTPB) {
+		for (uint32_t s = tid; s < total; s += NT) {
 			int lo = 0, hi = NRC;  // largest c with cstart[c] <= s
 			while (hi - lo > 1) {
 				const int mid = (lo + hi) >> 1;
@@ -205,9 +216,11 @@ __global__ void __launch_bounds__(LTPB, 2) k_force_lj_brick(ForceParams P, int n
 	__syncthreads();
 
 	const double rc2 = P.rc2, eps24 = P.eps24, sig2 = P.sig2, shift6 = P.shift6;
+	const int half = tid % SPLIT;
+	const int nmy = (NROWS - half + SPLIT - 1) / SPLIT;  // neighbour rows of this lane
 	double u6_tot = 0., vir_tot = 0.;
-	for (uint32_t base = 0; base < n_i; base += LTPB) {  // one pass unless the brick is over-full
-		const uint32_t it = base + tid;
+	for (uint32_t base = 0; base < n_i; base += NT / SPLIT) {  // one pass unless the brick is over-full
+		const uint32_t it = base + (uint32_t)(tid / SPLIT);
 		const bool active = it < n_i;
 		LjAcc acc = {0., 0., 0., 0., 0.};
 		uint32_t gi = 0;
@@ -224,6 +237,7 @@ __global__ void __launch_bounds__(LTPB, 2) k_force_lj_brick(ForceParams P, int n
 			const uint32_t k = it - bstart[lo];
 			const uint32_t ii = cstart[rcell] + k;
 			gi = gbeg[rcell] + k;
+			const int rowbase = ((rzc - HW) * RY + (ryc - HW)) * RX + (rxc - HW);  // row 0 of the neighbourhood
 			if (staged) {
 				const double xi = sx[ii], yi = sy[ii], zi = sz[ii];
 				uint32_t cnt = 0;  // hits found (may exceed CAPL: then the list is incomplete and the lane re-evaluates directly)
@@ -233,43 +247,40 @@ __global__ void __launch_bounds__(LTPB, 2) k_force_lj_brick(ForceParams P, int n
 				constexpr int U = 4;
 				const uint32_t lane_off = (uint32_t)tid * 2u;  // byte offset of this lane inside a list row
 				char* const lst_bytes = reinterpret_cast<char*>(lst);
+				for (int kk = 0; kk < nmy; ++kk) {
+					const int row = kk * SPLIT + half;
+					const int r0 = rowbase + (row / NW) * (RY * RX) + (row % NW) * RX;
+					const uint32_t jb = cstart[r0], je = cstart[r0 + NW];
+					const uint32_t self = (row == OWNROW) ? ii : 0xffffffffu;  // the molecule itself lives in one row only
+					double ax[U], ay[U], az[U], bxv[U], byv[U], bzv[U];
 #pragma unroll
-				for (int dz = -HW; dz <= HW; ++dz) {
+					for (int u = 0; u < U; ++u) {  // reads past `je` stay inside the padded staging arrays
+						ax[u] = sx[jb + u];
+						ay[u] = sy[jb + u];
+						az[u] = sz[jb + u];
+					}
+					for (uint32_t j0 = jb; j0 < je; j0 += U) {
 #pragma unroll
-					for (int dy = -HW; dy <= HW; ++dy) {
-						const int r0 = ((rzc + dz) * RY + (ryc + dy)) * RX + (rxc - HW);
-						const uint32_t jb = cstart[r0], je = cstart[r0 + 2 * HW + 1];
-						double ax[U], ay[U], az[U], bxv[U], byv[U], bzv[U];
-#pragma unroll
-						for (int u = 0; u < U; ++u) {  // reads past `je` stay inside the padded staging arrays
-							ax[u] = sx[jb + u];
-							ay[u] = sy[jb + u];
-							az[u] = sz[jb + u];
+						for (int u = 0; u < U; ++u) {
+							bxv[u] = sx[j0 + U + u];
+							byv[u] = sy[j0 + U + u];
+							bzv[u] = sz[j0 + U + u];
 						}
-						for (uint32_t j0 = jb; j0 < je; j0 += U) {
+						const uint32_t nvalid = je - j0;
 #pragma unroll
-							for (int u = 0; u < U; ++u) {
-								bxv[u] = sx[j0 + U + u];
-								byv[u] = sy[j0 + U + u];
-								bzv[u] = sz[j0 + U + u];
-							}
-							const uint32_t nvalid = je - j0;
+						for (int u = 0; u < U; ++u) {
+							const double dx = xi - ax[u], dyy = yi - ay[u], dzz = zi - az[u];
+							const double r2 = fma(dzz, dzz, fma(dyy, dyy, dx * dx));
+							const bool hit = (r2 < rc2) & ((uint32_t)u < nvalid) & (j0 + u != self);
+							const uint32_t slot = min(hit ? cnt : (uint32_t)CAPL, (uint32_t)CAPL);
+							*reinterpret_cast<uint16_t*>(lst_bytes + ((slot << LSHIFT) | lane_off)) = (uint16_t)(j0 + u);
+							cnt += hit ? 1u : 0u;
+						}
 #pragma unroll
-							for (int u = 0; u < U; ++u) {
-								const double dx = xi - ax[u], dyy = yi - ay[u], dzz = zi - az[u];
-								const double r2 = fma(dzz, dzz, fma(dyy, dyy, dx * dx));
-								bool hit = (r2 < rc2) & ((uint32_t)u < nvalid);
-								if (dz == 0 && dy == 0) hit &= (j0 + u != ii);  // self lives in the own row only
-								const uint32_t slot = min(hit ? cnt : (uint32_t)CAPL, (uint32_t)CAPL);
-								*reinterpret_cast<uint16_t*>(lst_bytes + ((slot << 9) | lane_off)) = (uint16_t)(j0 + u);
-								cnt += hit ? 1u : 0u;
-							}
-#pragma unroll
-							for (int u = 0; u < U; ++u) {
-								ax[u] = bxv[u];
-								ay[u] = byv[u];
-								az[u] = bzv[u];
-							}
+						for (int u = 0; u < U; ++u) {
+							ax[u] = bxv[u];
+							ay[u] = byv[u];
+							az[u] = bzv[u];
 						}
 					}
 				}
@@ -280,7 +291,7 @@ __global__ void __launch_bounds__(LTPB, 2) k_force_lj_brick(ForceParams P, int n
 					for (; s2 + 4 <= cnt; s2 += 4) {
 						uint32_t jj[4];
 #pragma unroll
-						for (int u = 0; u < 4; ++u) jj[u] = *reinterpret_cast<uint16_t*>(lst_bytes + (((s2 + u) << 9) | lane_off));
+						for (int u = 0; u < 4; ++u) jj[u] = *reinterpret_cast<uint16_t*>(lst_bytes + (((s2 + u) << LSHIFT) | lane_off));
 						double px[4], py[4], pz[4];
 #pragma unroll
 						for (int u = 0; u < 4; ++u) {
@@ -292,33 +303,41 @@ __global__ void __launch_bounds__(LTPB, 2) k_force_lj_brick(ForceParams P, int n
 						for (int u = 0; u < 4; ++u) lj_pair_in(xi, yi, zi, px[u], py[u], pz[u], eps24, sig2, acc, slj);
 					}
 					for (; s2 < cnt; ++s2) {
-						const uint32_t j = *reinterpret_cast<uint16_t*>(lst_bytes + ((s2 << 9) | lane_off));
+						const uint32_t j = *reinterpret_cast<uint16_t*>(lst_bytes + ((s2 << LSHIFT) | lane_off));
 						lj_pair_in(xi, yi, zi, sx[j], sy[j], sz[j], eps24, sig2, acc, slj);
 					}
 					acc.u6 = fma(eps24, slj, shift6 * (double)cnt);
 				} else {
-					// list overflow (very dense neighbourhood): direct evaluation of this molecule
-					for (int dz = -HW; dz <= HW; ++dz)
-						for (int dy = -HW; dy <= HW; ++dy) {
-							const int r0 = ((rzc + dz) * RY + (ryc + dy)) * RX + (rxc - HW);
-							const uint32_t jb = cstart[r0], je = cstart[r0 + 2 * HW + 1];
-							for (uint32_t j = jb; j < je; ++j)
-								if (j != ii) lj_pair(xi, yi, zi, sx[j], sy[j], sz[j], rc2, eps24, sig2, shift6, acc);
-						}
+					// list overflow (very dense neighbourhood): direct evaluation of this lane's rows
+					for (int kk = 0; kk < nmy; ++kk) {
+						const int row = kk * SPLIT + half;
+						const int r0 = rowbase + (row / NW) * (RY * RX) + (row % NW) * RX;
+						const uint32_t jb = cstart[r0], je = cstart[r0 + NW];
+						for (uint32_t j = jb; j < je; ++j)
+							if (j != ii) lj_pair(xi, yi, zi, sx[j], sy[j], sz[j], rc2, eps24, sig2, shift6, acc);
+					}
 				}
 			} else {
 				// shell does not fit LDS (pathological density): same arithmetic straight from global memory
 				const double xi = P.x[gi], yi = P.y[gi], zi = P.z[gi];
-				for (int dz = -HW; dz <= HW; ++dz)
-					for (int dy = -HW; dy <= HW; ++dy) {
-						const int r0 = ((rzc + dz) * RY + (ryc + dy)) * RX + (rxc - HW);
-						for (int c = r0; c <= r0 + 2 * HW; ++c) {
-							const uint32_t gb = gbeg[c], n = cstart[c + 1] - cstart[c];
-							for (uint32_t j = gb; j < gb + n; ++j)
-								if (j != gi) lj_pair(xi, yi, zi, P.x[j], P.y[j], P.z[j], rc2, eps24, sig2, shift6, acc);
-						}
+				for (int kk = 0; kk < nmy; ++kk) {
+					const int row = kk * SPLIT + half;
+					const int r0 = rowbase + (row / NW) * (RY * RX) + (row % NW) * RX;
+					for (int c = r0; c < r0 + NW; ++c) {
+						const uint32_t gb = gbeg[c], n = cstart[c + 1] - cstart[c];
+						for (uint32_t j = gb; j < gb + n; ++j)
+							if (j != gi) lj_pair(xi, yi, zi, P.x[j], P.y[j], P.z[j], rc2, eps24, sig2, shift6, acc);
 					}
+				}
 			}
+		}
+		// combine the partial forces of the SPLIT lanes that share a molecule (adjacent lanes); lane `half == 0` stores
+		if (SPLIT == 2) {
+			acc.fx += __shfl_xor(acc.fx, 1);
+			acc.fy += __shfl_xor(acc.fy, 1);
+			acc.fz += __shfl_xor(acc.fz, 1);
+		}
+		if (active && half == 0) {
 			P.Fx[gi] = acc.fx;
 			P.Fy[gi] = acc.fy;
 			P.Fz[gi] = acc.fz;
@@ -336,33 +355,40 @@ __global__ void __launch_bounds__(LTPB, 2) k_force_lj_brick(ForceParams P, int n
 	__syncthreads();
 	if (tid == 0) {
 		double* out = P.partials + (size_t)blockIdx.x * 4;
-		out[0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+		double su = 0., sv = 0.;
+		for (int i = 0; i < NT / 64; ++i) {
+			su += red[i][0];
+			sv += red[i][1];
+		}
+		out[0] = su;
 		out[1] = 0.;
 		out[2] = 0.;
-		out[3] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+		out[3] = sv;
 	}
 }
 
-bool launch_force_lj(const ForceParams& p, hipStream_t s, uint32_t* nblocks, double* partials, size_t partials_cap) {
-	(void)partials;
+template <int HW, int BX, int BY, int BZ, int CAPJ, int CAPL, int SPLIT>
+static bool launch_brick(const ForceParams& p, hipStream_t s, uint32_t* nblocks, size_t partials_cap) {
 	const Grid& g = p.g;
-	if (g.hw == 1) {
-		constexpr int BX = 4, BY = 2, BZ = 2;
-		const int nbx = (g.box[0] + BX - 1) / BX, nby = (g.box[1] + BY - 1) / BY, nbz = (g.box[2] + BZ - 1) / BZ;
-		const long nb = 8 * (((long)nbx * nby * nbz + 7) / 8);
-		if (nb <= 0 || (size_t)nb > partials_cap || nb > 0x7fffffffL) return false;
-		*nblocks = (uint32_t)nb;
-		hipLaunchKernelGGL((k_force_lj_brick<1, BX, BY, BZ, 1656, 71>), dim3((uint32_t)nb), dim3(LTPB), 0, s, p, nbx, nby, nbz);
-		return true;
+	const int nbx = (g.box[0] + BX - 1) / BX, nby = (g.box[1] + BY - 1) / BY, nbz = (g.box[2] + BZ - 1) / BZ;
+	const long nb = 8 * (((long)nbx * nby * nbz + 7) / 8);
+	if (nb <= 0 || (size_t)nb > partials_cap || nb > 0x7fffffffL) return false;
+	*nblocks = (uint32_t)nb;
+	hipLaunchKernelGGL((k_force_lj_brick<HW, BX, BY, BZ, CAPJ, CAPL, SPLIT>), dim3((uint32_t)nb), dim3(LTPB * SPLIT), 0, s,
+					   p, nbx, nby, nbz);
+	return true;
+}
+
+bool launch_force_lj(const ForceParams& p, hipStream_t s, uint32_t* nblocks, double* partials, size_t partials_cap,
+					 int split) {
+	(void)partials;
+	if (p.g.hw == 1) {
+		if (split == 2) return launch_brick<1, 4, 2, 2, 1616, 38, 2>(p, s, nblocks, partials_cap);
+		return launch_brick<1, 4, 2, 2, 1656, 71, 1>(p, s, nblocks, partials_cap);
 	}
-	if (g.hw == 2) {
-		constexpr int BX = 8, BY = 4, BZ = 4;
-		const int nbx = (g.box[0] + BX - 1) / BX, nby = (g.box[1] + BY - 1) / BY, nbz = (g.box[2] + BZ - 1) / BZ;
-		const long nb = 8 * (((long)nbx * nby * nbz + 7) / 8);
-		if (nb <= 0 || (size_t)nb > partials_cap || nb > 0x7fffffffL) return false;
-		*nblocks = (uint32_t)nb;
-		hipLaunchKernelGGL((k_force_lj_brick<2, BX, BY, BZ, 1528, 63>), dim3((uint32_t)nb), dim3(LTPB), 0, s, p, nbx, nby, nbz);
-		return true;
+	if (p.g.hw == 2) {
+		if (split == 2) return launch_brick<2, 8, 4, 4, 1440, 38, 2>(p, s, nblocks, partials_cap);
+		return launch_brick<2, 8, 4, 4, 1528, 63, 1>(p, s, nblocks, partials_cap);
 	}
 	return false;
 }

@@ -32,9 +32,10 @@ def by_id(d, ids):
     return {k: (v[o] if v is not None else None) for k, v in d.items()}
 
 
-def run_forces(ps, st, rc, periodic, kernel=0, vi=True, cic=1):
+def run_forces(ps, st, rc, periodic, kernel=0, vi=True, cic=1, split=2):
     cont = make_container(ps, rc, periodic, cellsInCutoffRadius=cic)
     cont.engine.set_option("force_kernel", kernel)
+    cont.engine.set_option("lj_split", split)
     cont.engine.set_option("compute_vi", 1 if vi else 0)
     dom = mirror.Domain(ps.length)
     cp = mirror.VectorizedCellProcessor(dom, rc, rc)
@@ -290,16 +291,17 @@ def test_seam_a_soa_forces_matches_reference():
 LJ1_CASES = ["U0", "F0", "U0_periodic", "lj1clj", "bcc1clj_3456", "bcc1clj_16000"]
 
 
+@pytest.mark.parametrize("split", [1, 2])
 @pytest.mark.parametrize("cic", [1, 2])
 @pytest.mark.parametrize("name", LJ1_CASES)
-def test_lds_kernel_matches_reference_golden(name, cic):
+def test_lds_kernel_matches_reference_golden(name, cic, split):
     case = MAN[name]
     g = read_golden(name)
     ps = inp.read_inp(input_path(case["input"]))
     st = sorted_phase_space(ps)
     if cic == 2 and np.min(ps.length) < 2 * case["rc"] * 0.5 * 2:
         pass  # tiny boxes still work with half-size cells (at least one cell per dimension)
-    out = run_forces(ps, st, case["rc"], bool(case["periodic"]), kernel=capi.FK_LDS_LIST, vi=False, cic=cic)
+    out = run_forces(ps, st, case["rc"], bool(case["periodic"]), kernel=capi.FK_LDS_LIST, vi=False, cic=cic, split=split)
     assert out["container"].engine.get_option("force_kernel") == capi.FK_LDS_LIST
     rec = g["recs"]
     fl = FORCE_FLOOR.get(name, 0.0)
@@ -318,12 +320,12 @@ def test_lds_kernel_equals_generic_kernel_large_box():
                         r, v, np.tile([1., 0, 0, 0], (N, 1)), np.zeros((N, 3)))
     st = sorted_phase_space(ps)
     gen = run_forces(ps, st, 2.5, True, kernel=capi.FK_GENERIC, vi=False)
-    for cic in (1, 2):
-        lds = run_forces(ps, st, 2.5, True, kernel=capi.FK_LDS_LIST, vi=False, cic=cic)
+    for cic, split in ((1, 1), (1, 2), (2, 1), (2, 2)):
+        lds = run_forces(ps, st, 2.5, True, kernel=capi.FK_LDS_LIST, vi=False, cic=cic, split=split)
         assert rel_max(lds["F"], gen["F"]) < 1e-13
         assert abs(lds["upot"] - gen["upot"]) < 1e-12 * abs(gen["upot"])
         assert abs(lds["virial"] - gen["virial"]) < 1e-12 * abs(gen["virial"])
-        again = run_forces(ps, st, 2.5, True, kernel=capi.FK_LDS_LIST, vi=False, cic=cic)
+        again = run_forces(ps, st, 2.5, True, kernel=capi.FK_LDS_LIST, vi=False, cic=cic, split=split)
         assert np.array_equal(again["F"], lds["F"]) and again["upot"] == lds["upot"]
         cont = lds["container"]
         dom = mirror.Domain(ps.length)
@@ -348,6 +350,7 @@ def test_lds_kernel_dense_cluster_fallbacks():
                         r, np.zeros((N, 3)), np.tile([1., 0, 0, 0], (N, 1)), np.zeros((N, 3)))
     st = sorted_phase_space(ps)
     gen = run_forces(ps, st, 2.5, True, kernel=capi.FK_GENERIC, vi=False)
-    lds = run_forces(ps, st, 2.5, True, kernel=capi.FK_LDS_LIST, vi=False)
-    assert rel_max(lds["F"], gen["F"]) < 1e-12
-    assert abs(lds["upot"] - gen["upot"]) < 1e-12 * abs(gen["upot"])
+    for split in (1, 2):
+        lds = run_forces(ps, st, 2.5, True, kernel=capi.FK_LDS_LIST, vi=False, split=split)
+        assert rel_max(lds["F"], gen["F"]) < 1e-12
+        assert abs(lds["upot"] - gen["upot"]) < 1e-12 * abs(gen["upot"])

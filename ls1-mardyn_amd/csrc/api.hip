@@ -626,6 +626,7 @@ static HaloArgs halo_args(ls1hip_ctx* c) {
 static int do_rebin_finish(ls1hip_ctx* c, uint32_t n_in) {
 	RebinArgs a = rebin_args(c, n_in);
 	launch_rebin_sort_gather(a, c->stream);
+	HIPCHK(c, hipGetLastError());
 	c->cur ^= 1;
 	c->binned = true;
 	c->halo_valid = false;
@@ -640,6 +641,7 @@ extern "C" int ls1hip_rebin(ls1hip_ctx* c) {
 	TimedScope ts(c, c->t_rebin);
 	RebinArgs a = rebin_args(c, (uint32_t)c->n_real);
 	launch_rebin_classify(a, c->stream);
+	HIPCHK(c, hipGetLastError());
 	c->pending_in = (uint32_t)c->n_real;
 	if (!c->has_remote) return do_rebin_finish(c, (uint32_t)c->n_real);
 	c->binned = false;
@@ -657,6 +659,7 @@ extern "C" int ls1hip_halo(ls1hip_ctx* c) {
 		launch_halo_finalize(a, c->stream);
 		c->halo_valid = true;
 	}
+	HIPCHK(c, hipGetLastError());
 	c->forces_valid = false;
 	return LS1HIP_OK;
 }
@@ -693,6 +696,7 @@ static int launch_forces(ls1hip_ctx* c, int which) {
 		launch_force_generic(P, c->one_clj, c->opt_vi != 0, c->h_ct.has_rot != 0, c->stream, &nblocks);
 	}
 	launch_force_reduce(c->d_cnt, c->d_partials, nblocks, c->d_stage, c->stream);
+	HIPCHK(c, hipGetLastError());
 	return LS1HIP_OK;
 }
 
@@ -741,6 +745,7 @@ extern "C" int ls1hip_kick_drift(ls1hip_ctx* c, double dt) {
 	HIPCHK(c, hipSetDevice(c->device));
 	TimedScope ts(c, c->t_integrate);
 	launch_kick_drift(integ_args(c, dt), c->stream);
+	HIPCHK(c, hipGetLastError());
 	c->binned = false;
 	c->halo_valid = false;
 	c->forces_valid = false;

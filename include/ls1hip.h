@@ -148,6 +148,16 @@ int ls1hip_forces(ls1hip_ctx* ctx, int which, double* upot, double* virial);
  * v += dt_half/m F; L += dt_half M; returns sum m v^2, sum I w^2, N, rotational DOF (thermostat 0). */
 int ls1hip_kick(ls1hip_ctx* ctx, double dt_half, double* summv2, double* sumIw2, uint64_t* n, uint64_t* rot_dof);
 
+/* VelocityScalingThermostat::apply, global branch (thermostats/VelocityScalingThermostat.cpp:80-96): v *= beta_trans,
+ * D *= beta_rot for every owned molecule. */
+int ls1hip_scale_velocities(ls1hip_ctx* ctx, double beta_trans, double beta_rot);
+
+/* Global velocity-scaling thermostat inside ls1hip_run: after every post-force kick the device computes
+ * beta_trans = (3 N T / sum m v^2)^0.4, beta_rot = (rotDOF T / sum I w^2)^0.4 exactly as Domain::calculateGlobalValues
+ * does for thermostat 0 (Domain.cpp:204-240) and applies them, without a host round trip.  enabled = 0 -> NVE.
+ * (Single-rank domains; multi-rank hosts reduce the sums and call ls1hip_scale_velocities.) */
+int ls1hip_set_thermostat(ls1hip_ctx* ctx, int enabled, double target_temperature);
+
 /* nsteps full time steps entirely on the device (single rank, all directions local), no host round trip
  * inside: the loop body of Simulation::simulate (Simulation.cpp:979-1167) for an NVE run without plugins.
  * out6 (may be NULL) = {upot, virial, summv2, sumIw2, N, rotDOF} of the LAST step. */

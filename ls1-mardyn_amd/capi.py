@@ -41,6 +41,8 @@ SYMBOLS = {
     "ls1hip_halo": (C.c_int, [C.c_void_p]),
     "ls1hip_forces": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp]),
     "ls1hip_kick": (C.c_int, [C.c_void_p, C.c_double, _dp, _dp, _u64p, _u64p]),
+    "ls1hip_scale_velocities": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "ls1hip_set_thermostat": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     "ls1hip_run": (C.c_int, [C.c_void_p, C.c_double, C.c_ulong, _dp]),
     "ls1hip_export_counts": (C.c_int, [C.c_void_p, C.c_int, _u64p]),
     "ls1hip_export_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),

@@ -761,7 +761,7 @@ extern "C" int ls1hip_kick(ls1hip_ctx* c, double dt_half, double* summv2, double
 		TimedScope ts(c, c->t_integrate);
 		uint32_t nb = 0;
 		launch_kick(integ_args(c, dt_half), c->stream, &nb);
-		launch_kin_reduce(c->d_cnt, c->d_partials, nb, c->stream);
+		launch_kin_reduce(c->d_cnt, c->d_partials, nb, c->stream, c->thermostat_on ? c->thermostat_T : 0.);
 	}
 	if (summv2 || sumIw2 || n || rot_dof) {
 		int rc = sync_counters(c);
@@ -774,6 +774,24 @@ extern "C" int ls1hip_kick(ls1hip_ctx* c, double dt_half, double* summv2, double
 	return LS1HIP_OK;
 }
 
+extern "C" int ls1hip_scale_velocities(ls1hip_ctx* c, double beta_trans, double beta_rot) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, c->cap_real, "no molecules uploaded");
+	HIPCHK(c, hipSetDevice(c->device));
+	TimedScope ts(c, c->t_integrate);
+	launch_scale(integ_args(c, 0.), beta_trans, beta_rot, false, c->stream);
+	HIPCHK(c, hipGetLastError());
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_set_thermostat(ls1hip_ctx* c, int enabled, double target_temperature) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, !enabled || target_temperature > 0., "target temperature must be positive");
+	c->thermostat_on = enabled != 0;
+	c->thermostat_T = target_temperature;
+	return LS1HIP_OK;
+}
+
 extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double* out6) {
 	if (!c) return LS1HIP_EINVAL;
 	REQUIRE(c, !c->has_remote, "ls1hip_run drives single-rank domains only (use the piecewise calls with a transport)");
@@ -782,6 +800,15 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 	for (unsigned long s = 0; s < nsteps; ++s) {
 		int rc;
 		if (s == 0) {
+			if ((rc = ls1hip_kick_drift(c, dt))) return rc;
+		} else if (c->thermostat_on) {
+			// NVT: the scaling factors depend on the kinetic sums after the kick, so the two half kicks stay separate
+			// passes: kick (+ sums, betas on the device) -> scale -> kick+drift   (Simulation.cpp:1099-1131)
+			if ((rc = ls1hip_kick(c, 0.5 * dt, nullptr, nullptr, nullptr, nullptr))) return rc;
+			{
+				TimedScope ts(c, c->t_integrate);
+				launch_scale(integ_args(c, 0.), 1., 1., true, c->stream);
+			}
 			if ((rc = ls1hip_kick_drift(c, dt))) return rc;
 		} else {
 			// post-force kick of step s-1 fused with the pre-force kick+drift of step s (same F, one pass)
@@ -792,7 +819,13 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 			c->forces_valid = false;
 		}
 		if ((rc = ls1hip_rebin(c)) || (rc = ls1hip_halo(c)) || (rc = ls1hip_forces(c, 0, nullptr, nullptr))) return rc;
-		if (s + 1 == nsteps && (rc = ls1hip_kick(c, 0.5 * dt, nullptr, nullptr, nullptr, nullptr))) return rc;
+		if (s + 1 == nsteps) {
+			if ((rc = ls1hip_kick(c, 0.5 * dt, nullptr, nullptr, nullptr, nullptr))) return rc;
+			if (c->thermostat_on) {
+				TimedScope ts(c, c->t_integrate);
+				launch_scale(integ_args(c, 0.), 1., 1., true, c->stream);
+			}
+		}
 	}
 	int rc = sync_counters(c);
 	if (rc) return rc;

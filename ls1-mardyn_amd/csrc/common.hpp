@@ -50,6 +50,7 @@ struct DevCounters {
 	unsigned long long dist_checks, pairs_in_range;
 	double macro[4];       // u6, uX, rf, virial of the current traversal
 	double kin[2];         // sum m v^2, sum I w^2
+	double beta[2];        // thermostat factors derived from kin (beta_trans, beta_rot)
 	unsigned long long kin_n, kin_rotdof;
 };
 
@@ -122,6 +123,8 @@ struct ls1hip_ctx {
 	double* d_exp_halo = nullptr;   // per-direction slices, LS1HIP_HALO_DOUBLES per record
 	uint32_t exp_off_leave[28], exp_off_halo[28];
 	bool forces_valid = false, halo_valid = false, binned = false;
+	bool thermostat_on = false;
+	double thermostat_T = 0.;
 	// timing
 	bool timing_on = false;
 	ls1::Timer t_force, t_integrate, t_rebin, t_halo;
@@ -194,6 +197,7 @@ struct IntegArgs {
 void launch_kick_drift(const IntegArgs& a, hipStream_t s);
 void launch_kick(const IntegArgs& a, hipStream_t s, uint32_t* nblocks);
 void launch_kick_then_kick_drift(const IntegArgs& a, hipStream_t s);
-void launch_kin_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, hipStream_t s);
+void launch_kin_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, hipStream_t s, double target_T);
+void launch_scale(const IntegArgs& a, double beta_trans, double beta_rot, bool from_device, hipStream_t s);
 
 }  // namespace ls1

@@ -189,7 +189,7 @@ void launch_kick(const IntegArgs& a, hipStream_t s, uint32_t* nblocks) {
 	else hipLaunchKernelGGL(k_kick<false>, dim3(nb), dim3(ITPB), 0, s, a);
 }
 
-__global__ void __launch_bounds__(256) k_kin_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks) {
+__global__ void __launch_bounds__(256) k_kin_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, double target_T) {
 	double v[3] = {0., 0., 0.};
 	for (uint32_t b = threadIdx.x; b < nblocks; b += 256)
 		for (int k = 0; k < 3; ++k) v[k] += partials[(size_t)b * 4 + k];
@@ -204,12 +204,46 @@ __global__ void __launch_bounds__(256) k_kin_reduce(DevCounters* cnt, const doub
 		cnt->kin[1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
 		cnt->kin_n = cnt->n_real;
 		cnt->kin_rotdof = (unsigned long long)(red[0][2] + red[1][2] + red[2][2] + red[3][2] + 0.5);
+		// thermostat 0 of Domain::calculateGlobalValues (Domain.cpp:225-240)
+		double bt = 1., br = 1.;
+		if (target_T > 0. && cnt->kin_n > 0) {
+			bt = pow(3.0 * (double)cnt->kin_n * target_T / cnt->kin[0], 0.4);
+			br = (cnt->kin[1] == 0.) ? 1.0 : pow((double)cnt->kin_rotdof * target_T / cnt->kin[1], 0.4);
+		}
+		cnt->beta[0] = bt;
+		cnt->beta[1] = br;
 	}
 }
 
-void launch_kin_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, hipStream_t s) {
+// VelocityScalingThermostat::apply (global betas): v *= beta_trans, D *= beta_rot
+template <bool HAS_ROT>
+__global__ void __launch_bounds__(ITPB) k_scale(IntegArgs a, double bt, double br, bool from_device) {
+	const uint32_t p = blockIdx.x * ITPB + threadIdx.x;
+	if (p >= a.cnt->n_real) return;
+	if (from_device) {
+		bt = a.cnt->beta[0];
+		br = a.cnt->beta[1];
+	}
+	a.mol.vx[p] *= bt;
+	a.mol.vy[p] *= bt;
+	a.mol.vz[p] *= bt;
+	if (HAS_ROT) {
+		a.mol.Dx[p] *= br;
+		a.mol.Dy[p] *= br;
+		a.mol.Dz[p] *= br;
+	}
+}
+
+void launch_scale(const IntegArgs& a, double beta_trans, double beta_rot, bool from_device, hipStream_t s) {
+	if (a.n_cap == 0) return;
+	const dim3 grid((a.n_cap + ITPB - 1) / ITPB);
+	if (a.has_rot) hipLaunchKernelGGL(k_scale<true>, grid, dim3(ITPB), 0, s, a, beta_trans, beta_rot, from_device);
+	else hipLaunchKernelGGL(k_scale<false>, grid, dim3(ITPB), 0, s, a, beta_trans, beta_rot, from_device);
+}
+
+void launch_kin_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, hipStream_t s, double target_T) {
 	if (nblocks == 0) return;
-	hipLaunchKernelGGL(k_kin_reduce, dim3(1), dim3(256), 0, s, cnt, partials, nblocks);
+	hipLaunchKernelGGL(k_kin_reduce, dim3(1), dim3(256), 0, s, cnt, partials, nblocks, target_T);
 }
 
 }  // namespace ls1

@@ -144,6 +144,12 @@ class DeviceEngine:
         self._chk(self.lib.ls1hip_kick(self.ctx, float(dt_half), C.byref(a), C.byref(b), C.byref(n), C.byref(rd)))
         return a.value, b.value, n.value, rd.value
 
+    def scale_velocities(self, beta_trans, beta_rot=1.0):
+        self._chk(self.lib.ls1hip_scale_velocities(self.ctx, float(beta_trans), float(beta_rot)))
+
+    def set_thermostat(self, enabled: bool, target_temperature: float = 0.0):
+        self._chk(self.lib.ls1hip_set_thermostat(self.ctx, int(bool(enabled)), float(target_temperature)))
+
     def run(self, dt, nsteps):
         out = np.zeros(6)
         self._chk(self.lib.ls1hip_run(self.ctx, float(dt), int(nsteps), capi.dptr(out)))

@@ -63,6 +63,34 @@ class Domain:
     def getLocalSummv2(self, thermostat=0):
         return self._local2KETrans[thermostat]
 
+    # --- Domain::calculateGlobalValues, thermostat 0, single rank (Domain.cpp:151-240)
+    def setGlobalTemperature(self, T):
+        self._universalTargetTemperature = float(T)
+
+    def calculateGlobalValues(self, domainDecomp=None, particleContainer=None, collectThermostatVelocities=True,
+                              Tfactor=1.0):
+        self._globalUpot = self._localUpot
+        self._globalVirial = self._localVirial
+        N, rotDOF = self._localN[0], self._localRotDOF[0]
+        summv2 = self._local2KETrans[0]
+        sumIw2 = self._local2KERot[0] if rotDOF > 0 else 0.0
+        self._globalTemperature = (summv2 + sumIw2) / (3 * N + rotDOF) if N > 0 else 0.0
+        Ti = Tfactor * getattr(self, "_universalTargetTemperature", 0.0)
+        if Ti > 0.0 and N > 0:
+            self._universalBTrans = (3.0 * N * Ti / summv2) ** 0.4
+            self._universalBRot = 1.0 if sumIw2 == 0.0 else (rotDOF * Ti / sumIw2) ** 0.4
+        else:
+            self._universalBTrans = self._universalBRot = 1.0
+
+    def getGlobalBetaTrans(self):
+        return self._universalBTrans
+
+    def getGlobalBetaRot(self):
+        return self._universalBRot
+
+    def getGlobalCurrentTemperature(self):
+        return self._globalTemperature
+
     def getLocalSumIw2(self, thermostat=0):
         return self._local2KERot[thermostat]
 
@@ -247,8 +275,26 @@ class Leapfrog(Integrator):
             self._state = self.STATE_POST_FORCE_CALCULATION
 
 
+class VelocityScalingThermostat:
+    """thermostats/VelocityScalingThermostat.cpp:9-96, global (non component-wise) branch."""
+
+    def __init__(self):
+        self._globalBetaTrans = 1.0
+        self._globalBetaRot = 1.0
+
+    def setGlobalBetaTrans(self, beta):
+        self._globalBetaTrans = float(beta)
+
+    def setGlobalBetaRot(self, beta):
+        self._globalBetaRot = float(beta)
+
+    def apply(self, moleculeContainer: LinkedCells):
+        moleculeContainer.engine.scale_velocities(self._globalBetaTrans, self._globalBetaRot)
+
+
 def simulate(container: LinkedCells, decomp: DomainDecompBase, cellProcessor: VectorizedCellProcessor,
-             integrator: Leapfrog, domain: Domain, nsteps: int, initial_forces: bool = True):
+             integrator: Leapfrog, domain: Domain, nsteps: int, initial_forces: bool = True,
+             thermostat: VelocityScalingThermostat | None = None):
     """The hot-path part of Simulation::prepare_start / simulate (Simulation.cpp:813-892, 979-1167), call for call."""
     if initial_forces:
         container.update()
@@ -264,3 +310,8 @@ def simulate(container: LinkedCells, decomp: DomainDecompBase, cellProcessor: Ve
         container.traverseCells(cellProcessor)
         container.deleteOuterParticles()
         integrator.eventForcesCalculated(container, domain)
+        if thermostat is not None:  # Simulation.cpp:1099-1131
+            domain.calculateGlobalValues(decomp, container, True, 1.0)
+            thermostat.setGlobalBetaTrans(domain.getGlobalBetaTrans())
+            thermostat.setGlobalBetaRot(domain.getGlobalBetaRot())
+            thermostat.apply(container)

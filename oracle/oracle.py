@@ -110,7 +110,23 @@ class Oracle:
         lib().ls1o_upd_postF(self.h, len(v), float(dt_half), _i(cid), _d(v), _d(q), _d(D), _d(F), _d(M), _d(s))
         return float(s[0]), float(s[1])
 
-    def step(self, dt, cid, r, v, q, D, F, M, L, periodic=True):
+    @staticmethod
+    def global_betas(summv2, sumIw2, n, rot_dof, target_T, tfactor=1.0):
+        """Domain::calculateGlobalValues, thermostat 0 (/root/reference/src/Domain.cpp:225-240)."""
+        Ti = tfactor * target_T
+        if Ti > 0.0 and n > 0:
+            bt = (3.0 * n * Ti / summv2) ** 0.4
+            br = 1.0 if sumIw2 == 0.0 else (rot_dof * Ti / sumIw2) ** 0.4
+            return bt, br
+        return 1.0, 1.0
+
+    def rot_dof(self, cid):
+        """Sum of Component::getRotationalDegreesOfFreedom over the molecules (Leapfrog.cpp:126)."""
+        I = np.asarray(self.flat["I"]).reshape(-1, 3)
+        per_comp = (I != 0.0).sum(axis=1)
+        return int(per_comp[np.asarray(cid)].sum())
+
+    def step(self, dt, cid, r, v, q, D, F, M, L, periodic=True, target_T=None):
         """One full time step in the reference's order (Simulation.cpp:995-1099): pre-force kick+drift,
         wrap + halo + forces, post-force kick.  Arrays are updated in place; returns the force dict."""
         self.upd_preF(dt, cid, r, v, q, D, F, M)
@@ -119,4 +135,10 @@ class Oracle:
         out = self.forces(r, q, cid, L, periodic)
         F[:] = out["F"]; M[:] = out["M"]
         out["summv2"], out["sumIw2"] = self.upd_postF(0.5 * dt, cid, v, q, D, F, M)
+        if target_T is not None:
+            # VelocityScalingThermostat::apply, global branch (thermostats/VelocityScalingThermostat.cpp:80-96)
+            bt, br = self.global_betas(out["summv2"], out["sumIw2"], len(r), self.rot_dof(cid), target_T)
+            v *= bt
+            D *= br
+            out["beta_trans"], out["beta_rot"] = bt, br
         return out

@@ -12,7 +12,9 @@
 // (/root/reference/src/particleContainer/tests/LinkedCellsTest.cpp:511-600) and of the time step in
 // Simulation::simulate (/root/reference/src/Simulation.cpp:995-1099).
 //
-// usage: refdump <file.inp> <cutoff> <periodic 0|1> <out.bin> [--legacy] [--steps N --dt DT]
+// usage: refdump <file.inp> <cutoff> <periodic 0|1> <out.bin> [--legacy] [--steps N --dt DT] [--nvt]
+//   --nvt: global velocity-scaling thermostat after every step, exactly the sequence of Simulation::simulate
+//          (Simulation.cpp:1099-1131): calculateGlobalValues -> VelocityScalingThermostat::apply (global betas)
 // output (little-endian): magic "LS1GOLD1", u64 N, u64 nsteps, f64 cutoff, f64 dt, f64 L[3],
 //   f64 upot, f64 virial, f64 summv2, f64 sumIw2, then N records sorted by molecule id:
 //   u64 id, u64 cid, f64 r[3], v[3], q[4], D[3], F[3], M[3], Vi[3]
@@ -29,6 +31,7 @@
 #include "particleContainer/adapter/LegacyCellProcessor.h"
 #include "particleContainer/adapter/ParticlePairs2PotForceAdapter.h"
 #include "particleContainer/adapter/VectorizedCellProcessor.h"
+#include "thermostats/VelocityScalingThermostat.h"
 #include "utils/Logger.h"
 
 #include <algorithm>
@@ -66,10 +69,12 @@ int main(int argc, char** argv) {
 	bool legacy = false;
 	unsigned long nsteps = 0;
 	double dt = 0.0;
+	bool nvt = false;
 	for (int a = 5; a < argc; ++a) {
 		if (!strcmp(argv[a], "--legacy")) legacy = true;
 		else if (!strcmp(argv[a], "--steps")) nsteps = strtoul(argv[++a], nullptr, 10);
 		else if (!strcmp(argv[a], "--dt")) dt = atof(argv[++a]);
+		else if (!strcmp(argv[a], "--nvt")) nvt = true;
 	}
 
 	new Simulation();  // assigns global_simulation
@@ -114,6 +119,13 @@ int main(int argc, char** argv) {
 			integ.eventNewTimestep(c, domain);
 			forces(c, dd, domain, cp, periodic);
 			integ.eventForcesCalculated(c, domain);
+			if (nvt) {
+				domain->calculateGlobalValues(dd, c, true, 1.0);
+				VelocityScalingThermostat vst;
+				vst.setGlobalBetaTrans(domain->getGlobalBetaTrans());
+				vst.setGlobalBetaRot(domain->getGlobalBetaRot());
+				vst.apply(c);
+			}
 		}
 	}
 	// kinetic sums exactly as Leapfrog::transition2to3 accumulates them (Leapfrog.cpp:120-128 -> FullMolecule.cpp:366-389)

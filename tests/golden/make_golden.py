@@ -54,6 +54,9 @@ CASES = [
     ("bcc1clj_3456", "synthetic:bcc1clj:12", 2.5, 1, 0, 0.0, 0),
     ("bcc1clj_3456_steps10", "synthetic:bcc1clj:12", 2.5, 1, 10, 0.005, 0),
     ("bcc1clj_16000", "synthetic:bcc1clj:20", 2.5, 1, 0, 0.0, 0),
+    # global velocity-scaling thermostat active (legacy flag value 2 = --nvt): SURVEY 8f-1
+    ("bcc1clj_3456_nvt10", "synthetic:bcc1clj:12", 2.5, 1, 10, 0.005, 2),
+    ("ethan_nvt5", "Ethan_equilibrated.inp", 32.1254, 1, 5, 0.5, 2),
 ]
 
 
@@ -122,8 +125,10 @@ def main():
             src = tmp
         out = os.path.join(HERE, name + ".bin")
         cmd = [REFDUMP, src, repr(rc), str(periodic), out]
-        if legacy:
+        if legacy == 1:
             cmd.append("--legacy")
+        if legacy == 2:
+            cmd.append("--nvt")
         if steps:
             cmd += ["--steps", str(steps), "--dt", repr(dt)]
         env = dict(os.environ, OMP_NUM_THREADS="4")

@@ -21,7 +21,7 @@ def manifest():
                 continue
             name, inp, rc, periodic, steps, dt, legacy = ln.split()
             out[name] = dict(name=name, input=inp, rc=float(rc), periodic=int(periodic), steps=int(steps),
-                             dt=float(dt), legacy=int(legacy))
+                             dt=float(dt), legacy=int(int(legacy) == 1), nvt=int(int(legacy) == 2))
     return out
 
 

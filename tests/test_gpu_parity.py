@@ -119,7 +119,11 @@ def test_trajectory_matches_reference(name):
     integ = mirror.Leapfrog(case["dt"])
     q = st["q"] / np.linalg.norm(st["q"], axis=1, keepdims=True)
     cont.addParticles(st["ids"], st["cid"], st["r"], st["v"], q, st["D"])
-    mirror.simulate(cont, dd, cp, integ, dom, case["steps"])
+    thermo = None
+    if case["nvt"]:
+        dom.setGlobalTemperature(ps.temperature)
+        thermo = mirror.VelocityScalingThermostat()
+    mirror.simulate(cont, dd, cp, integ, dom, case["steps"], thermostat=thermo)
     mol = cont.molecules()
     o = np.argsort(mol["ids"], kind="stable")
     rec = g["recs"]
@@ -135,9 +139,38 @@ def test_trajectory_matches_reference(name):
     assert rel_max(F, rec["F"]) < 1e-8
     assert abs(dom.getLocalUpot() - g["upot"]) / abs(g["upot"]) < 1e-9
     assert abs(dom.getLocalVirial() - g["virial"]) / abs(g["virial"]) < 1e-8
-    assert abs(dom.getLocalSummv2() - g["summv2"]) / abs(g["summv2"]) < 1e-9
+    bt2 = dom.getGlobalBetaTrans() ** 2 if case["nvt"] else 1.0  # golden sums are taken after the last scaling
+    br2 = dom.getGlobalBetaRot() ** 2 if case["nvt"] else 1.0
+    assert abs(dom.getLocalSummv2() * bt2 - g["summv2"]) / abs(g["summv2"]) < 1e-9
     if g["sumIw2"] != 0:
-        assert abs(dom.getLocalSumIw2() - g["sumIw2"]) / abs(g["sumIw2"]) < 1e-9
+        assert abs(dom.getLocalSumIw2() * br2 - g["sumIw2"]) / abs(g["sumIw2"]) < 1e-9
+
+
+@pytest.mark.parametrize("name", [k for k, c in MAN.items() if c["nvt"]])
+def test_device_nvt_loop_matches_reference(name):
+    """ls1hip_run with the on-device global velocity-scaling thermostat (no host round trips) vs the reference."""
+    case = MAN[name]
+    g = read_golden(name)
+    ps = inp.read_inp(input_path(case["input"]))
+    st = sorted_phase_space(ps)
+    cont = make_container(ps, case["rc"], True)
+    dom = mirror.Domain(ps.length)
+    cp = mirror.VectorizedCellProcessor(dom, case["rc"], case["rc"])
+    q = st["q"] / np.linalg.norm(st["q"], axis=1, keepdims=True)
+    cont.addParticles(st["ids"], st["cid"], st["r"], st["v"], q, st["D"])
+    mirror.simulate(cont, mirror.DomainDecompBase(), cp, mirror.Leapfrog(case["dt"]), dom, 0)
+    cont.engine.set_thermostat(True, ps.temperature)
+    out = cont.engine.run(case["dt"], case["steps"])
+    mol = cont.molecules()
+    o = np.argsort(mol["ids"], kind="stable")
+    rec = g["recs"]
+    assert rel_max(mol["v"][o], rec["v"]) < 1e-9
+    dr = mol["r"][o] - rec["r"]
+    dr -= ps.length * np.round(dr / ps.length)
+    assert np.max(np.abs(dr)) < 1e-9 * np.max(ps.length)
+    if np.max(np.abs(rec["D"])) > 0:
+        assert rel_max(mol["D"][o], rec["D"]) < 1e-9
+    assert abs(out["upot"] - g["upot"]) / abs(g["upot"]) < 1e-9
 
 
 def test_device_loop_equals_piecewise_calls():

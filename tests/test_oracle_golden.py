@@ -71,8 +71,13 @@ def test_trajectory_matches_reference(name):
     q /= np.linalg.norm(q, axis=1, keepdims=True)
     out = orc.forces(r, q, cid, L, periodic=True)
     F, M = out["F"].copy(), out["M"].copy()
+    T = ps.temperature if case["nvt"] else None
     for _ in range(case["steps"]):
-        out = orc.step(case["dt"], cid, r, v, q, D, F, M, L, periodic=True)
+        out = orc.step(case["dt"], cid, r, v, q, D, F, M, L, periodic=True, target_T=T)
+    if case["nvt"]:
+        # the golden kinetic sums are taken after the final velocity scaling
+        out["summv2"] *= out["beta_trans"] ** 2
+        out["sumIw2"] *= out["beta_rot"] ** 2
     rec = g["recs"]
     # positions modulo the box (a molecule sitting exactly on a face may be represented on either side)
     dr = r - rec["r"]

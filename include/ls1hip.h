@@ -158,6 +158,13 @@ int ls1hip_scale_velocities(ls1hip_ctx* ctx, double beta_trans, double beta_rot)
  * (Single-rank domains; multi-rank hosts reduce the sums and call ls1hip_scale_velocities.) */
 int ls1hip_set_thermostat(ls1hip_ctx* ctx, int enabled, double target_temperature);
 
+/* Homogeneous long-range correction: the constants Homogeneous::init / calculateLongRange compute and
+ * hand to Domain::setUpotCorr / setVirialCorr (longRange/Homogeneous.cpp:21-135; LJ tail integrals of Lustig 1988,
+ * :137-180; dipole reaction-field self term).  Host arithmetic on the component tables of this context.
+ * n_per_component[ncomp]: global molecule count per component; global_rho = N / V. */
+int ls1hip_long_range_homogeneous(ls1hip_ctx* ctx, const uint64_t* n_per_component, double global_rho,
+								  double* upot_corr, double* virial_corr);
+
 /* nsteps full time steps entirely on the device (single rank, all directions local), no host round trip
  * inside: the loop body of Simulation::simulate (Simulation.cpp:979-1167) for an NVE run without plugins.
  * out6 (may be NULL) = {upot, virial, summv2, sumIw2, N, rotDOF} of the LAST step. */

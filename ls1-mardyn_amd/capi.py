@@ -43,6 +43,7 @@ SYMBOLS = {
     "ls1hip_kick": (C.c_int, [C.c_void_p, C.c_double, _dp, _dp, _u64p, _u64p]),
     "ls1hip_scale_velocities": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "ls1hip_set_thermostat": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "ls1hip_long_range_homogeneous": (C.c_int, [C.c_void_p, _u64p, C.c_double, _dp, _dp]),
     "ls1hip_run": (C.c_int, [C.c_void_p, C.c_double, C.c_ulong, _dp]),
     "ls1hip_export_counts": (C.c_int, [C.c_void_p, C.c_int, _u64p]),
     "ls1hip_export_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),

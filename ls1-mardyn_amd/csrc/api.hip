@@ -792,6 +792,87 @@ extern "C" int ls1hip_set_thermostat(ls1hip_ctx* c, int enabled, double target_t
 	return LS1HIP_OK;
 }
 
+// ---- Homogeneous long-range correction: longRange/Homogeneous.cpp ---------------------------------------------------
+namespace lrc {
+static double TICCu(int n, double rc, double s2) { return -pow(rc, 2 * n + 3) / (pow(s2, n) * (2 * n + 3)); }
+static double TICSu(int n, double rc, double s2, double tau) {
+	return -(pow(rc + tau, 2 * n + 3) - pow(rc - tau, 2 * n + 3)) * rc / (4 * pow(s2, n) * tau * (n + 1) * (2 * n + 3)) +
+		   (pow(rc + tau, 2 * n + 4) - pow(rc - tau, 2 * n + 4)) / (4 * pow(s2, n) * tau * (n + 1) * (2 * n + 3) * (2 * n + 4));
+}
+static double TISSu(int n, double rc, double s2, double t1, double t2) {
+	const double tp = t1 + t2, tm = t1 - t2;
+	return -(pow(rc + tp, 2 * n + 4) - pow(rc + tm, 2 * n + 4) - pow(rc - tm, 2 * n + 4) + pow(rc - tp, 2 * n + 4)) * rc /
+			   (8 * pow(s2, n) * t1 * t2 * (n + 1) * (2 * n + 3) * (2 * n + 4)) +
+		   (pow(rc + tp, 2 * n + 5) - pow(rc + tm, 2 * n + 5) - pow(rc - tm, 2 * n + 5) + pow(rc - tp, 2 * n + 5)) /
+			   (8 * pow(s2, n) * t1 * t2 * (n + 1) * (2 * n + 3) * (2 * n + 4) * (2 * n + 5));
+}
+static double TICCv(int n, double rc, double s2) { return 2 * n * TICCu(n, rc, s2); }
+static double TICSv(int n, double rc, double s2, double tau) {
+	return -(pow(rc + tau, 2 * n + 2) - pow(rc - tau, 2 * n + 2)) * rc * rc / (4 * pow(s2, n) * tau * (n + 1)) -
+		   3 * TICSu(n, rc, s2, tau);
+}
+static double TISSv(int n, double rc, double s2, double t1, double t2) {
+	const double tp = t1 + t2, tm = t1 - t2;
+	return -(pow(rc + tp, 2 * n + 3) - pow(rc + tm, 2 * n + 3) - pow(rc - tm, 2 * n + 3) + pow(rc - tp, 2 * n + 3)) * rc * rc /
+			   (8 * pow(s2, n) * t1 * t2 * (n + 1) * (2 * n + 3)) -
+		   3 * TISSu(n, rc, s2, t1, t2);
+}
+}  // namespace lrc
+
+extern "C" int ls1hip_long_range_homogeneous(ls1hip_ctx* c, const uint64_t* nmol, double rho, double* upot_corr,
+											 double* virial_corr) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, c->have_comp, "ls1hip_set_components must be called first");
+	REQUIRE(c, nmol && rho > 0., "bad argument");
+	const CompTable& t = c->h_ct;
+	double U = 0., V = 0., self = 0., N = 0.;
+	const double rc = c->rc_lj;
+	for (int i = 0; i < t.ncomp; ++i) N += (double)nmol[i];
+	REQUIRE(c, N > 0., "no molecules");
+	for (int i = 0; i < t.ncomp; ++i) {
+		// effective dipole of the component: point charges + point dipoles (Homogeneous.cpp:38-64)
+		double cb[3] = {0., 0., 0.};
+		for (int a = 0; a < t.nc[i]; ++a)
+			for (int d = 0; d < 3; ++d) cb[d] += t.chq[t.oc[i] + a] * t.chpos[t.oc[i] + a][d];
+		for (int a = 0; a < t.nd[i]; ++a) {
+			const double* e = t.dpe[t.od[i] + a];
+			const double norm = 1.0 / sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+			for (int d = 0; d < 3; ++d) cb[d] += t.dpmy[t.od[i] + a] * e[d] * norm;
+		}
+		self += (cb[0] * cb[0] + cb[1] * cb[1] + cb[2] * cb[2]) * (double)nmol[i];
+		for (int j = 0; j < t.ncomp; ++j)
+			for (int a = 0; a < t.nlj[i]; ++a) {
+				const double* pa = t.ljpos[t.olj[i] + a];
+				const double tau1 = sqrt(pa[0] * pa[0] + pa[1] * pa[1] + pa[2] * pa[2]);
+				for (int b = 0; b < t.nlj[j]; ++b) {
+					const double* pb = t.ljpos[t.olj[j] + b];
+					double tau2 = sqrt(pb[0] * pb[0] + pb[1] * pb[1] + pb[2] * pb[2]);
+					REQUIRE(c, tau1 + tau2 < rc, "error calculating cutoff corrections, rc too small");  // :83-86
+					const int k = (t.olj[i] + a) * t.ncenters + (t.olj[j] + b);
+					if (t.shift6[k] != 0.0) continue;  // truncated-shifted pairs carry no tail correction (:93)
+					const double fac = (double)nmol[i] * (double)nmol[j] * t.eps24[k], s2 = t.sig2[k];
+					if (tau1 == 0. && tau2 == 0.) {
+						U += fac * (lrc::TICCu(-6, rc, s2) - lrc::TICCu(-3, rc, s2));
+						V += fac * (lrc::TICCv(-6, rc, s2) - lrc::TICCv(-3, rc, s2));
+					} else if (tau1 != 0. && tau2 != 0.) {
+						U += fac * (lrc::TISSu(-6, rc, s2, tau1, tau2) - lrc::TISSu(-3, rc, s2, tau1, tau2));
+						V += fac * (lrc::TISSv(-6, rc, s2, tau1, tau2) - lrc::TISSv(-3, rc, s2, tau1, tau2));
+					} else {
+						if (tau2 == 0.) tau2 = tau1;
+						U += fac * (lrc::TICSu(-6, rc, s2, tau2) - lrc::TICSu(-3, rc, s2, tau2));
+						V += fac * (lrc::TICSv(-6, rc, s2, tau2) - lrc::TICSv(-3, rc, s2, tau2));
+					}
+				}
+			}
+	}
+	// Homogeneous::calculateLongRange (:113-135)
+	const double fac = M_PI * rho / (3. * N);
+	const double selfterm = -0.5 * t.epsRFInvrc3 * self;
+	if (upot_corr) *upot_corr = fac * U + selfterm;
+	if (virial_corr) *virial_corr = -fac * V + 3. * selfterm;
+	return LS1HIP_OK;
+}
+
 extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double* out6) {
 	if (!c) return LS1HIP_EINVAL;
 	REQUIRE(c, !c->has_remote, "ls1hip_run drives single-rank domains only (use the piecewise calls with a transport)");

@@ -150,6 +150,13 @@ class DeviceEngine:
     def set_thermostat(self, enabled: bool, target_temperature: float = 0.0):
         self._chk(self.lib.ls1hip_set_thermostat(self.ctx, int(bool(enabled)), float(target_temperature)))
 
+    def long_range_homogeneous(self, n_per_component, global_rho):
+        n = np.ascontiguousarray(n_per_component, dtype=np.uint64)
+        u = C.c_double(); w = C.c_double()
+        self._chk(self.lib.ls1hip_long_range_homogeneous(self.ctx, n.ctypes.data_as(capi._u64p), float(global_rho),
+                                                         C.byref(u), C.byref(w)))
+        return u.value, w.value
+
     def run(self, dt, nsteps):
         out = np.zeros(6)
         self._chk(self.lib.ls1hip_run(self.ctx, float(dt), int(nsteps), capi.dptr(out)))

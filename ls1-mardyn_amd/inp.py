@@ -264,3 +264,50 @@ def write_inp(path: str, ps: PhaseSpace, lj_rows=None) -> None:
         for i in range(n):
             vals = list(ps.r[i]) + list(ps.v[i]) + list(ps.q[i]) + list(ps.D[i])
             fh.write(f"{int(ps.ids[i])}\t{int(ps.cid[i]) + 1}\t" + " ".join(repr(float(x)) for x in vals) + "\n")
+
+
+# ---- binary checkpoints ----------------------------------------------------------------------------
+# XML header written by Domain::writeCheckpointHeaderXML (/root/reference/src/Domain.cpp:572-595) + 116-byte records
+# written by FullMolecule::writeBinary (/root/reference/src/molecules/FullMolecule.cpp:451-473): id u64, component id
+# (1-based) u32, r[3], v[3], q[4]=(w,x,y,z), L[3] as f64, little endian, unpadded.  Reader: io/BinaryReader.cpp.
+CHECKPOINT_RECORD = np.dtype([("id", "<u8"), ("cid", "<u4"), ("r", "<f8", 3), ("v", "<f8", 3), ("q", "<f8", 4),
+                              ("D", "<f8", 3)])
+assert CHECKPOINT_RECORD.itemsize == 116
+
+
+def read_checkpoint(prefix: str, components: ComponentSet | None = None) -> PhaseSpace:
+    """Read `<prefix>.header.xml` + `<prefix>.dat`.  The component set is not part of a binary checkpoint (the
+    reference takes it from the XML config), so it is passed in."""
+    import xml.etree.ElementTree as ET
+
+    hdr = ET.parse(prefix + ".header.xml").getroot().find("headerinfo")
+    time = float(hdr.findtext("time"))
+    ln = hdr.find("length")
+    length = np.array([float(ln.findtext(k)) for k in ("x", "y", "z")])
+    n = int(hdr.findtext("number"))
+    fmt = hdr.find("format").get("type")
+    if fmt != "ICRVQD":
+        raise ValueError(f"unsupported binary molecule format {fmt!r}")
+    rec = np.fromfile(prefix + ".dat", dtype=CHECKPOINT_RECORD)
+    if len(rec) != n:
+        raise ValueError(f"{prefix}.dat holds {len(rec)} records, header says {n}")
+    comps = components if components is not None else ComponentSet([], np.zeros((0, 2)), 0.0)
+    return PhaseSpace(comps, length, rec["id"].astype(np.uint64), rec["cid"].astype(np.int32) - 1,
+                      np.ascontiguousarray(rec["r"]), np.ascontiguousarray(rec["v"]), np.ascontiguousarray(rec["q"]),
+                      np.ascontiguousarray(rec["D"]), time, 0.0)
+
+
+def write_checkpoint(prefix: str, ps: PhaseSpace) -> None:
+    """Write the reference's binary checkpoint pair (same header text layout, same record bytes)."""
+    n = len(ps.ids)
+    e = lambda x: f"{float(x):21.15e}"  # FORMAT_SCI_MAX_DIGITS_WIDTH_21  # noqa: E731
+    with open(prefix + ".header.xml", "w") as fh:
+        fh.write("<?xml version='1.0' encoding='UTF-8'?>\n<mardyn version=\"20100525\" >\n\t<headerinfo>\n")
+        fh.write(f"\t\t<time>{e(ps.time)}</time>\n\t\t<length>\n")
+        fh.write(f"\t\t\t<x>{e(ps.length[0])}</x> <y>{e(ps.length[1])}</y> <z>{e(ps.length[2])}</z>\n")
+        fh.write(f"\t\t</length>\n\t\t<number>{n}</number>\n\t\t<format type=\"ICRVQD\"/>\n\t</headerinfo>\n</mardyn>\n")
+    rec = np.zeros(n, dtype=CHECKPOINT_RECORD)
+    rec["id"] = ps.ids
+    rec["cid"] = np.asarray(ps.cid, dtype=np.uint32) + 1
+    rec["r"], rec["v"], rec["q"], rec["D"] = ps.r, ps.v, ps.q, ps.D
+    rec.tofile(prefix + ".dat")

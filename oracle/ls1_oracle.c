@@ -898,3 +898,89 @@ void ls1o_upd_postF(const ls1o_sys *s, size_t n, double dt_halve, const int *cid
 	sums2[0] = summv2;
 	sums2[1] = sumIw2;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Homogeneous long-range correction: longRange/Homogeneous.cpp:21-135 (init + calculateLongRange),
+ * integrals _TICCu/_TICSu/_TISSu/_TICCv/_TICSv/_TISSv :137-180 (Lustig 1988).  nmol[c] = molecules of component c,
+ * rho = N/V.  out2 = {UpotCorr, VirialCorr} as Domain::setUpotCorr / setVirialCorr receive them.
+ * ----------------------------------------------------------------------------------------------------------------*/
+static double ticcu(int n, double rc, double s2) { return -pow(rc, 2 * n + 3) / (pow(s2, n) * (2 * n + 3)); }
+static double ticsu(int n, double rc, double s2, double tau) {
+	return -(pow(rc + tau, 2 * n + 3) - pow(rc - tau, 2 * n + 3)) * rc / (4 * pow(s2, n) * tau * (n + 1) * (2 * n + 3)) +
+		   (pow(rc + tau, 2 * n + 4) - pow(rc - tau, 2 * n + 4)) / (4 * pow(s2, n) * tau * (n + 1) * (2 * n + 3) * (2 * n + 4));
+}
+static double tissu(int n, double rc, double s2, double t1, double t2) {
+	const double tp = t1 + t2, tm = t1 - t2;
+	return -(pow(rc + tp, 2 * n + 4) - pow(rc + tm, 2 * n + 4) - pow(rc - tm, 2 * n + 4) + pow(rc - tp, 2 * n + 4)) * rc /
+			   (8 * pow(s2, n) * t1 * t2 * (n + 1) * (2 * n + 3) * (2 * n + 4)) +
+		   (pow(rc + tp, 2 * n + 5) - pow(rc + tm, 2 * n + 5) - pow(rc - tm, 2 * n + 5) + pow(rc - tp, 2 * n + 5)) /
+			   (8 * pow(s2, n) * t1 * t2 * (n + 1) * (2 * n + 3) * (2 * n + 4) * (2 * n + 5));
+}
+static double ticcv(int n, double rc, double s2) { return 2 * n * ticcu(n, rc, s2); }
+static double ticsv(int n, double rc, double s2, double tau) {
+	return -(pow(rc + tau, 2 * n + 2) - pow(rc - tau, 2 * n + 2)) * rc * rc / (4 * pow(s2, n) * tau * (n + 1)) -
+		   3 * ticsu(n, rc, s2, tau);
+}
+static double tissv(int n, double rc, double s2, double t1, double t2) {
+	const double tp = t1 + t2, tm = t1 - t2;
+	return -(pow(rc + tp, 2 * n + 3) - pow(rc + tm, 2 * n + 3) - pow(rc - tm, 2 * n + 3) + pow(rc - tp, 2 * n + 3)) * rc * rc /
+			   (8 * pow(s2, n) * t1 * t2 * (n + 1) * (2 * n + 3)) -
+		   3 * tissu(n, rc, s2, t1, t2);
+}
+
+int ls1o_lrc_homogeneous(const ls1o_sys *s, const unsigned long *nmol, double *out2) {
+	double UpotCorrLJ = 0., VirialCorrLJ = 0., MySelbstTerm = 0.;
+	unsigned long N = 0;
+	for (int i = 0; i < s->ncomp; ++i) N += nmol[i];
+	for (int i = 0; i < s->ncomp; ++i) {
+		double cb[3] = {0., 0., 0.};
+		for (int a = 0; a < s->nc[i]; ++a) {
+			const double *c = s->ch + (size_t)(s->oc[i] + a) * CH_STRIDE;
+			for (int d = 0; d < 3; ++d) cb[d] += c[4] * c[d];
+		}
+		for (int a = 0; a < s->nd[i]; ++a) {
+			const double *p = s->dp + (size_t)(s->od[i] + a) * DP_STRIDE;
+			const double norm = 1.0 / sqrt(p[3] * p[3] + p[4] * p[4] + p[5] * p[5]);
+			for (int d = 0; d < 3; ++d) cb[d] += p[6] * p[3 + d] * norm;
+		}
+		MySelbstTerm += (cb[0] * cb[0] + cb[1] * cb[1] + cb[2] * cb[2]) * (double)nmol[i];
+		for (int j = 0; j < s->ncomp; ++j)
+			for (int a = 0; a < s->nlj[i]; ++a) {
+				const double *sa = s->lj + (size_t)(s->olj[i] + a) * LJ_STRIDE;
+				const double tau1 = sqrt(sa[0] * sa[0] + sa[1] * sa[1] + sa[2] * sa[2]);
+				for (int b = 0; b < s->nlj[j]; ++b) {
+					const double *sb = s->lj + (size_t)(s->olj[j] + b) * LJ_STRIDE;
+					double tau2 = sqrt(sb[0] * sb[0] + sb[1] * sb[1] + sb[2] * sb[2]);
+					if (tau1 + tau2 >= s->rcLJ) return -1;
+					const size_t k = (size_t)(s->olj[i] + a) * s->ncenters + (s->olj[j] + b);
+					if (s->shift6[k] != 0.0) continue;
+					const double fac = (double)nmol[i] * (double)nmol[j] * s->eps24[k], s2 = s->sig2[k], rc = s->rcLJ;
+					if (tau1 == 0. && tau2 == 0.) {
+						UpotCorrLJ += fac * (ticcu(-6, rc, s2) - ticcu(-3, rc, s2));
+						VirialCorrLJ += fac * (ticcv(-6, rc, s2) - ticcv(-3, rc, s2));
+					} else if (tau1 != 0. && tau2 != 0.) {
+						UpotCorrLJ += fac * (tissu(-6, rc, s2, tau1, tau2) - tissu(-3, rc, s2, tau1, tau2));
+						VirialCorrLJ += fac * (tissv(-6, rc, s2, tau1, tau2) - tissv(-3, rc, s2, tau1, tau2));
+					} else {
+						if (tau2 == 0.) tau2 = tau1;
+						UpotCorrLJ += fac * (ticsu(-6, rc, s2, tau2) - ticsu(-3, rc, s2, tau2));
+						VirialCorrLJ += fac * (ticsv(-6, rc, s2, tau2) - ticsv(-3, rc, s2, tau2));
+					}
+				}
+			}
+	}
+	(void)N;
+	out2[0] = UpotCorrLJ;
+	out2[1] = VirialCorrLJ;
+	out2[2] = MySelbstTerm;
+	return 0;
+}
+
+/* second half: Homogeneous::calculateLongRange (Homogeneous.cpp:113-135); in3 = the three sums of the first half */
+void ls1o_lrc_finish(const ls1o_sys *s, const double *in3, double rho, unsigned long N, double *out2) {
+	const double fac = 3.14159265358979323846 * rho / (3. * (double)N);
+	const double UpotCorrLJ = fac * in3[0], VirialCorrLJ = -fac * in3[1];
+	const double MySelbstTerm = -0.5 * s->epsRFInvrc3 * in3[2];
+	out2[0] = UpotCorrLJ + MySelbstTerm;
+	out2[1] = VirialCorrLJ + 3. * MySelbstTerm;
+}

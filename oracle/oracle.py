@@ -35,6 +35,9 @@ def lib():
         L.ls1o_wrap.argtypes = [C.c_size_t, _dp, _dp]
         L.ls1o_forces.restype = C.c_int
         L.ls1o_forces.argtypes = [C.c_void_p, C.c_size_t, _dp, _dp, _ip, C.c_int, _dp, _dp, _dp, _dp, _dp]
+        L.ls1o_lrc_homogeneous.restype = C.c_int
+        L.ls1o_lrc_homogeneous.argtypes = [C.c_void_p, C.POINTER(C.c_ulong), _dp]
+        L.ls1o_lrc_finish.argtypes = [C.c_void_p, _dp, C.c_double, C.c_ulong, _dp]
         L.ls1o_upd_preF.argtypes = [C.c_void_p, C.c_size_t, C.c_double, _ip, _dp, _dp, _dp, _dp, _dp, _dp]
         L.ls1o_upd_postF.argtypes = [C.c_void_p, C.c_size_t, C.c_double, _ip, _dp, _dp, _dp, _dp, _dp, _dp]
         _lib = L
@@ -99,6 +102,17 @@ class Oracle:
         if rc != 0:
             raise RuntimeError(f"ls1o_forces failed: {rc}")
         return dict(F=F, M=M, Vi=Vi, upot=out[0], virial=out[1], upot_lj=out[2], upot_x=out[3])
+
+    def lrc_homogeneous(self, cid, L):
+        """Homogeneous long-range correction (UpotCorr, VirialCorr) for the molecule set `cid` in box L."""
+        ncomp = int(self.flat["ncomp"])
+        nmol = (C.c_ulong * ncomp)(*[int((np.asarray(cid) == k).sum()) for k in range(ncomp)])
+        sums = np.zeros(3); out = np.zeros(2)
+        if lib().ls1o_lrc_homogeneous(self.h, nmol, _d(sums)) != 0:
+            raise RuntimeError("cutoff too small for the long-range correction")
+        N = len(cid)
+        lib().ls1o_lrc_finish(self.h, _d(sums), N / float(np.prod(L)), N, _d(out))
+        return float(out[0]), float(out[1])
 
     def upd_preF(self, dt, cid, r, v, q, D, F, M):
         cid = np.ascontiguousarray(cid, dtype=np.int32)

@@ -18,12 +18,15 @@
 // output (little-endian): magic "LS1GOLD1", u64 N, u64 nsteps, f64 cutoff, f64 dt, f64 L[3],
 //   f64 upot, f64 virial, f64 summv2, f64 sumIw2, then N records sorted by molecule id:
 //   u64 id, u64 cid, f64 r[3], v[3], q[4], D[3], F[3], M[3], Vi[3]
+//   then a trailer: magic "LS1LRC01", f64 upot_corr, f64 virial_corr = Homogeneous long-range correction of the INITIAL
+//   configuration (longRange/Homogeneous.cpp:21-135) as Domain::calculateGlobalValues adds it (Domain.cpp:176-181)
 //   (r,v,q,D = state at which F,M,Vi were evaluated, i.e. after nsteps full steps; v,D after the post-force kick
 //    when nsteps>0).
 #include "Simulation.h"
 #include "Domain.h"
 #include "ensemble/EnsembleBase.h"
 #include "integrators/Leapfrog.h"
+#include "longRange/Homogeneous.h"
 #include "io/ASCIIReader.h"
 #include "molecules/Molecule.h"
 #include "parallel/DomainDecompBase.h"
@@ -109,6 +112,18 @@ int main(int argc, char** argv) {
 	}
 
 	forces(c, dd, domain, cp, periodic);
+	double upotCorr = 0., virialCorr = 0.;
+	{
+		Homogeneous lrc(rc, rc, domain, global_simulation);
+		lrc.init();
+		lrc.calculateLongRange();
+		const double ul = domain->getLocalUpot(), vl = domain->getLocalVirial();
+		domain->calculateGlobalValues(dd, c, true, 1.0);
+		upotCorr = domain->getGlobalUpot() - ul;
+		virialCorr = domain->getAverageGlobalVirial() * (double)domain->getglobalNumMolecules() - vl;
+		domain->setUpotCorr(0.);
+		domain->setVirialCorr(0.);
+	}
 	double summv2 = 0., sumIw2 = 0.;
 	if (nsteps > 0) {
 		Leapfrog integ(dt);
@@ -170,8 +185,12 @@ int main(int argc, char** argv) {
 	fwrite(&summv2, 8, 1, f);
 	fwrite(&sumIw2, 8, 1, f);
 	fwrite(recs.data(), sizeof(Rec), recs.size(), f);
+	const char lmagic[8] = {'L', 'S', '1', 'L', 'R', 'C', '0', '1'};
+	fwrite(lmagic, 1, 8, f);
+	fwrite(&upotCorr, 8, 1, f);
+	fwrite(&virialCorr, 8, 1, f);
 	fclose(f);
-	printf("%s rc=%g periodic=%d legacy=%d steps=%lu N=%lu upot=%.17g virial=%.17g\n", file.c_str(), rc, (int)periodic,
-		   (int)legacy, nsteps, (unsigned long)n, upot, virial);
+	printf("%s rc=%g periodic=%d legacy=%d steps=%lu N=%lu upot=%.17g virial=%.17g lrc=(%.12g, %.12g)\n", file.c_str(), rc,
+		   (int)periodic, (int)legacy, nsteps, (unsigned long)n, upot, virial, upotCorr, virialCorr);
 	return 0;
 }

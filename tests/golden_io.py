@@ -31,10 +31,15 @@ def read_golden(name):
         assert fh.read(8) == b"LS1GOLD1"
         n, steps = np.frombuffer(fh.read(16), dtype="<u8")
         hdr = np.frombuffer(fh.read(8 * 9), dtype="<f8")
-        recs = np.frombuffer(fh.read(), dtype=REC)
+        body = fh.read()
+    lrc = None
+    if body[-24:-16] == b"LS1LRC01":
+        lrc = np.frombuffer(body[-16:], dtype="<f8").copy()
+        body = body[:-24]
+    recs = np.frombuffer(body, dtype=REC)
     assert len(recs) == n
     return dict(n=int(n), steps=int(steps), rc=hdr[0], dt=hdr[1], L=hdr[2:5].copy(), upot=hdr[5], virial=hdr[6],
-                summv2=hdr[7], sumIw2=hdr[8], recs=recs)
+                summv2=hdr[7], sumIw2=hdr[8], recs=recs, lrc=lrc)
 
 
 def input_path(fname):

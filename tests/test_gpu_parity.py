@@ -387,3 +387,17 @@ def test_lds_kernel_dense_cluster_fallbacks():
         lds = run_forces(ps, st, 2.5, True, kernel=capi.FK_LDS_LIST, vi=False, split=split)
         assert rel_max(lds["F"], gen["F"]) < 1e-12
         assert abs(lds["upot"] - gen["upot"]) < 1e-12 * abs(gen["upot"])
+
+
+@pytest.mark.parametrize("name", [k for k in FORCE_CASES])
+def test_homogeneous_long_range_correction(name):
+    """ls1hip_long_range_homogeneous vs the reference's Homogeneous LRC (golden trailer)."""
+    case = MAN[name]
+    g = read_golden(name)
+    ps = inp.read_inp(input_path(case["input"]))
+    cont = make_container(ps, case["rc"], bool(case["periodic"]))
+    ncomp = len(ps.components.components)
+    nmol = [int((ps.cid == k).sum()) for k in range(ncomp)]
+    u, v = cont.engine.long_range_homogeneous(nmol, len(ps.ids) / float(np.prod(ps.length)))
+    assert abs(u - g["lrc"][0]) <= 1e-12 * max(abs(g["lrc"][0]), abs(g["upot"]))
+    assert abs(v - g["lrc"][1]) <= 1e-12 * max(abs(g["lrc"][1]), abs(g["virial"]))

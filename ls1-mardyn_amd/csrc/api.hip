@@ -180,7 +180,7 @@ extern "C" int ls1hip_set_option(ls1hip_ctx* c, const char* name, long v) {
 	} else if (n == "count_pairs") {
 		c->opt_count_pairs = v ? 1 : 0;
 	} else if (n == "lj_split") {
-		REQUIRE(c, v == 1 || v == 2, "lj_split must be 1 or 2");
+		REQUIRE(c, v == 1 || v == 2 || v == 4 || v == 5, "lj_split must be 1, 2, 4 or 5 (4/5 = MFMA distance-tile pre-filter, 512/256 threads)");
 		c->opt_lj_split = v;
 	} else {
 		FAIL(c, LS1HIP_EINVAL, "unknown option '%s'", name);

@@ -367,6 +367,316 @@ __global__ void __launch_bounds__(LTPB * SPLIT, 2 * SPLIT) k_force_lj_brick(Forc
 	}
 }
 
+// ======================================================================================================================
+// k_force_lj_mfma — phase 1 as a dense r^2 tile on the matrix pipe.
+//
+// The candidate search is the one dense contraction on this path: for 16 owned molecules j and 16 candidates i,
+//     D[i][j] = sum_k A[i][k] B[k][j],   A[i] = (x_i, y_i, z_i, |r_i|^2),   B[.][j] = (-2x_j, -2y_j, -2z_j, 1)
+// is r_ij^2 - |r_j|^2 (K = 4): ONE v_mfma_f32_16x16x4_f32 evaluates 256 pair distances (FP32, brick-relative
+// coordinates), against ~8 VALU instructions per 64 distances in the scalar formulation.  It is used as a conservative
+// PRE-FILTER only (threshold rc^2 + rounding margin); phase 2 recomputes every listed pair in FP64 with the exact
+// strict mask, so forces / U / virial are those of the FP64 kernels.
+//
+// Mapping (v_mfma_f32_16x16x4_f32 register layout): lane l supplies A[i = l%16][k = l/16] and B[k = l/16][j = l%16] and
+// receives D[i = 4*(l/16) + r][j = l%16], r = 0..3.  So the four lanes {jo, jo+16, jo+32, jo+48} own molecule jo of the
+// tile and each sees a different quarter of every 16-candidate tile: the hit test needs ONE per-lane threshold
+// (rc^2 + margin - |r_j|^2), the per-lane lists are a quarter as long, and there is no cross-lane mask traffic.
+// Owned tile = the molecules of one cell (padded to 16); pencil bricks (1 x BY x BZ cells) make the 9 neighbour cells
+// of every z-plane ONE contiguous LDS range, so a cell has 3 candidate ranges of ~112 molecules = 7 tiles each.
+//
+// LDS: only FP64 data is staged (x, y, z absolute and |r_rel|^2, 32 B per molecule); the A operand is converted on
+// load ((float)(s4[k][i] - origin_k), 2 VALU per tile).  List entries are BYTE offsets (8 * index, u16) so phase 2 uses
+// them as LDS addresses directly.  The append is an unconditional store to slot `cnt` followed by cnt += hit
+// (v_cmp + v_addc): a miss is overwritten by the next store; cnt is clamped once per tile, which costs 4 spare rows.
+// ======================================================================================================================
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// masked pair for the MFMA kernel: out-of-range (and self, r2 == 0) pairs get r2 := 1e300, which drives every LJ term
+// to exactly 0 by underflow — one select instead of masking force and potential separately.
+__device__ __forceinline__ void lj_pair_m(double xi, double yi, double zi, double xj, double yj, double zj, double rc2,
+										  double eps24, double sig2, LjAcc& a, double& slj, uint32_t& nin) {
+	const double dx = xi - xj, dy = yi - yj, dz = zi - zj;
+	const double r2 = fma(dz, dz, fma(dy, dy, dx * dx));
+	const bool in = (r2 < rc2) & (r2 != 0.0);
+	const double inv = fast_rcp(in ? r2 : 1.0e300);
+	const double lj2 = sig2 * inv;
+	const double lj6 = lj2 * lj2 * lj2;
+	const double lj12 = lj6 * lj6;
+	const double lj12m6 = lj12 - lj6;
+	const double fac = eps24 * inv * (lj12 + lj12m6);
+	a.fx = fma(fac, dx, a.fx);
+	a.fy = fma(fac, dy, a.fy);
+	a.fz = fma(fac, dz, a.fz);
+	slj += lj12m6;
+	nin += in ? 1u : 0u;
+	a.vir = fma(fac, r2, a.vir);
+}
+
+template <int NT, int BY, int BZ, int CAPJ, int ROWS>
+__global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, int nbx, int nby, int nbz) {
+	constexpr int HW = 1, BX = 1;
+	constexpr int RX = BX + 2 * HW, RY = BY + 2 * HW, RZ = BZ + 2 * HW;
+	constexpr int NRC = RX * RY * RZ;
+	constexpr int NBC = BX * BY * BZ;
+	constexpr int NW = NT / 64;
+	constexpr int PLANE = 3 * RX;  // 9 cells of one z-plane of the neighbourhood are contiguous (RX == 3)
+	constexpr int PAD = 32;
+	constexpr int CAPS = CAPJ + PAD;
+	constexpr int RSH = (NT == 512) ? 10 : 9;   // list row stride = NT * 2 bytes
+	constexpr uint32_t CAPX = ROWS - 4;          // cnt is clamped to CAPX after every tile; cnt >= CAPX means overflow
+	static_assert(NT == 256 || NT == 512, "row stride shift");
+	static_assert(NBC % NW == 0, "cells must divide evenly over the waves");
+	static_assert(NRC <= NT * 4, "region too large for the block scan");
+	static_assert(CAPS * 8 <= 65536, "list entries are u16 byte offsets");
+	__shared__ double s4[4][CAPS];           // x, y, z (absolute) and |r_rel|^2 of every staged molecule
+	__shared__ uint16_t lst[ROWS * NT];      // per-lane candidate lists, slot-major
+	__shared__ uint32_t cstart[NRC + 1];
+	__shared__ uint32_t gbeg[NRC];
+	__shared__ uint32_t wsum[NW];
+	__shared__ double red[NW][2];
+
+	const int tid = threadIdx.x;
+	const int nb = nbx * nby * nbz;
+	const int chunk = gridDim.x / 8;
+	const int brick = (blockIdx.x % 8) * chunk + blockIdx.x / 8;  // XCD-aware brick order (see k_force_lj_brick)
+	bool live = brick < nb;
+	int bx = 0, by = 0, bz = 0;
+	if (live) {
+		bx = brick % nbx;
+		by = (brick / nbx) % nby;
+		bz = brick / (nbx * nby);
+	}
+	const int x0 = HW + bx * BX, y0 = HW + by * BY, z0 = HW + bz * BZ;
+	const int ex = min(BX, P.g.dims[0] - HW - x0), ey = min(BY, P.g.dims[1] - HW - y0), ez = min(BZ, P.g.dims[2] - HW - z0);
+	if (live && P.which != 0) {
+		const bool inner = x0 >= 2 * HW && y0 >= 2 * HW && z0 >= 2 * HW && x0 + ex <= P.g.dims[0] - 2 * HW &&
+						   y0 + ey <= P.g.dims[1] - 2 * HW && z0 + ez <= P.g.dims[2] - 2 * HW;
+		live = (P.which == 1) ? inner : !inner;
+	}
+	if (!live) {
+		if (tid < 4) P.partials[(size_t)blockIdx.x * 4 + tid] = 0.;
+		return;
+	}
+	// ---- region cell table + staging (as in k_force_lj_brick) ---------------------------------------------------------
+	for (int c = tid; c < NRC; c += NT) {
+		const int rx = c % RX, ry = (c / RX) % RY, rz = c / (RX * RY);
+		const int gx = x0 - HW + rx, gy = y0 - HW + ry, gz = z0 - HW + rz;
+		uint32_t b = 0, n = 0;
+		if (gx < P.g.dims[0] && gy < P.g.dims[1] && gz < P.g.dims[2]) {
+			const int gc = cell_index(P.g, gx, gy, gz);
+			b = P.cell_begin[gc];
+			n = P.cell_end[gc] - b;
+		}
+		gbeg[c] = b;
+		cstart[c] = n;
+	}
+	__syncthreads();
+	block_scan_lds<NT>(cstart, NRC, wsum);
+	const uint32_t total = cstart[NRC];
+	const bool staged = total <= (uint32_t)CAPJ;
+	// brick-relative origin: lower corner of the region's first cell
+	const double ox = P.g.bmin[0] + (double)(x0 - 2 * HW) * P.g.clen[0];
+	const double oy = P.g.bmin[1] + (double)(y0 - 2 * HW) * P.g.clen[1];
+	const double oz = P.g.bmin[2] + (double)(z0 - 2 * HW) * P.g.clen[2];
+	if (staged) {
+		for (uint32_t s = tid; s < total + PAD; s += NT) {
+			if (s < total) {
+				int lo = 0, hi = NRC;
+				while (hi - lo > 1) {
+					const int mid = (lo + hi) >> 1;
+					if (cstart[mid] <= s) lo = mid;
+					else hi = mid;
+				}
+				const uint32_t g = gbeg[lo] + (s - cstart[lo]);
+				const double x = P.x[g], y = P.y[g], z = P.z[g];
+				s4[0][s] = x;
+				s4[1][s] = y;
+				s4[2][s] = z;
+				const float fx = (float)(x - ox), fy = (float)(y - oy), fz = (float)(z - oz);
+				s4[3][s] = (double)(fx * fx + fy * fy + fz * fz);
+			} else {  // padding behind the last molecule: far away, never within the cutoff
+				s4[0][s] = ox;
+				s4[1][s] = oy;
+				s4[2][s] = oz;
+				s4[3][s] = 3.0e30;
+			}
+		}
+	}
+	__syncthreads();
+
+	const double rc2 = P.rc2, eps24 = P.eps24, sig2 = P.sig2, shift6 = P.shift6;
+	// conservative FP32 threshold: |D + |r_j|^2 - r^2| <= ~8 ulp of the largest term (2 E^2, E = region diagonal)
+	const float ext2 = (float)((RX * P.g.clen[0]) * (RX * P.g.clen[0]) + (RY * P.g.clen[1]) * (RY * P.g.clen[1]) +
+							   (RZ * P.g.clen[2]) * (RZ * P.g.clen[2]));
+	const float rc2m = (float)rc2 * (1.0f + 1e-6f) + 4e-6f * ext2;
+	const int lane = tid & 63, wv = tid >> 6;
+	const int jo = lane & 15, grp = lane >> 4;
+	const uint32_t lane_off = (uint32_t)tid * 2u;
+	char* const lst_bytes = reinterpret_cast<char*>(lst);
+	const char* const sxb = reinterpret_cast<const char*>(&s4[0][0]);
+	const char* const syb = reinterpret_cast<const char*>(&s4[1][0]);
+	const char* const szb = reinterpret_cast<const char*>(&s4[2][0]);
+	const double o_l = (grp == 0) ? ox : (grp == 1) ? oy : (grp == 2) ? oz : 0.0;  // origin of this lane's A component
+	const double* const arow = &s4[grp][jo];
+	double u6_tot = 0., vir_tot = 0.;
+
+	for (int cc = 0; cc < NBC / NW; ++cc) {              // every wave owns NBC/NW cells of the brick
+		const int c = wv * (NBC / NW) + cc;
+		const int cy = c % BY, cz = c / BY;                // BX == 1
+		if (cy >= ey || cz >= ez || ex < 1) continue;       // wave-uniform
+		const int rcell = ((cz + HW) * RY + (cy + HW)) * RX + HW;
+		const uint32_t ob = cstart[rcell], n_c = cstart[rcell + 1] - ob;
+		const uint32_t gb = gbeg[rcell];
+		for (uint32_t tb = 0; tb < n_c; tb += 16) {        // owned tiles of 16 molecules (one unless the cell is crowded)
+			const bool valid = tb + (uint32_t)jo < n_c;
+			const uint32_t oi = ob + tb + (uint32_t)jo;     // LDS index of the owned molecule of this lane
+			const uint32_t gi = gb + tb + (uint32_t)jo;     // its global index
+			LjAcc acc = {0., 0., 0., 0., 0.};
+			if (staged) {
+				// B operand (owned side) and per-lane threshold
+				float bval = (grp < 3) ? 0.f : 1.f;
+				float thr = -3.0e38f;
+				if (valid) {
+					const float own = (float)(s4[grp][oi] - o_l);
+					bval = (grp < 3) ? -2.f * own : 1.f;
+					thr = rc2m - (float)s4[3][oi];
+				}
+				uint32_t cnt = 0;
+				// ---- phase 1: MFMA distance tiles -> per-lane lists --------------------------------------------------
+				const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+				for (int dz = -1; dz <= 1; ++dz) {
+					const int r0 = ((cz + HW + dz) * RY + (cy + HW - 1)) * RX;  // first cell of the plane's 9-cell range
+					const uint32_t jb = (uint32_t)__builtin_amdgcn_readfirstlane((int)cstart[r0]);
+					const uint32_t je = (uint32_t)__builtin_amdgcn_readfirstlane((int)cstart[r0 + PLANE]);
+					if (jb >= je) continue;  // wave-uniform
+					const double* ap = arow + jb;
+					uint32_t cb8 = (jb + 4u * (uint32_t)grp) * 8u;  // byte offset of this lane's first candidate of the tile
+					double a_next = ap[0];
+					uint32_t t = jb;
+					for (; t + 16u < je; t += 16u) {  // full tiles: every candidate is real, no bound test
+						const float a = (float)(a_next - o_l);
+						ap += 16;
+						a_next = ap[0];
+						const floatx4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bval, zero, 0, 0, 0);
+#pragma unroll
+						for (int r = 0; r < 4; ++r) {
+							*reinterpret_cast<uint16_t*>(lst_bytes + ((cnt << RSH) | lane_off)) = (uint16_t)(cb8 + 8u * r);
+							cnt += (d[r] < thr) ? 1u : 0u;
+						}
+						cnt = min(cnt, CAPX);
+						cb8 += 128u;
+					}
+					{  // last (partial) tile of the range
+						const float a = (float)(a_next - o_l);
+						const floatx4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bval, zero, 0, 0, 0);
+						const uint32_t je8 = je * 8u;
+#pragma unroll
+						for (int r = 0; r < 4; ++r) {
+							const uint32_t c8 = cb8 + 8u * r;
+							*reinterpret_cast<uint16_t*>(lst_bytes + ((cnt << RSH) | lane_off)) = (uint16_t)c8;
+							cnt += ((d[r] < thr) & (c8 < je8)) ? 1u : 0u;
+						}
+						cnt = min(cnt, CAPX);
+					}
+				}
+				// ---- phase 2: exact FP64 evaluation of the listed pairs (strict mask; self pair has r2 == 0) --------
+				if (valid) {
+					const double xi = s4[0][oi], yi = s4[1][oi], zi = s4[2][oi];
+					if (cnt < CAPX) {
+						double slj = 0.;
+						uint32_t nin = 0;
+						uint32_t s2 = 0;
+						for (; s2 + 2 <= cnt; s2 += 2) {
+							const uint32_t ja = *reinterpret_cast<uint16_t*>(lst_bytes + ((s2 << RSH) | lane_off));
+							const uint32_t jc = *reinterpret_cast<uint16_t*>(lst_bytes + (((s2 + 1) << RSH) | lane_off));
+							const double xa = *reinterpret_cast<const double*>(sxb + ja);
+							const double ya = *reinterpret_cast<const double*>(syb + ja);
+							const double za = *reinterpret_cast<const double*>(szb + ja);
+							const double xb = *reinterpret_cast<const double*>(sxb + jc);
+							const double yb = *reinterpret_cast<const double*>(syb + jc);
+							const double zb = *reinterpret_cast<const double*>(szb + jc);
+							lj_pair_m(xi, yi, zi, xa, ya, za, rc2, eps24, sig2, acc, slj, nin);
+							lj_pair_m(xi, yi, zi, xb, yb, zb, rc2, eps24, sig2, acc, slj, nin);
+						}
+						if (s2 < cnt) {
+							const uint32_t ja = *reinterpret_cast<uint16_t*>(lst_bytes + ((s2 << RSH) | lane_off));
+							lj_pair_m(xi, yi, zi, *reinterpret_cast<const double*>(sxb + ja),
+									  *reinterpret_cast<const double*>(syb + ja), *reinterpret_cast<const double*>(szb + ja),
+									  rc2, eps24, sig2, acc, slj, nin);
+						}
+						acc.u6 = fma(eps24, slj, shift6 * (double)nin);
+					} else {
+						// list overflow (very dense neighbourhood): this lane evaluates its quarter of every tile directly
+						for (int dz = -1; dz <= 1; ++dz) {
+							const int r0 = ((cz + HW + dz) * RY + (cy + HW - 1)) * RX;
+							const uint32_t jb = cstart[r0], je = cstart[r0 + PLANE];
+							for (uint32_t t = jb; t < je; t += 16)
+								for (uint32_t r = 0; r < 4; ++r) {
+									const uint32_t j = t + 4u * (uint32_t)grp + r;
+									if (j < je) lj_pair(xi, yi, zi, s4[0][j], s4[1][j], s4[2][j], rc2, eps24, sig2, shift6, acc);
+								}
+						}
+					}
+				}
+			} else if (valid) {
+				// shell does not fit LDS (pathological density): quarter of the neighbour cells per lane, from global memory
+				const double xi = P.x[gi], yi = P.y[gi], zi = P.z[gi];
+				for (int dz = -1; dz <= 1; ++dz) {
+					const int r0 = ((cz + HW + dz) * RY + (cy + HW - 1)) * RX;
+					for (int k = r0 + grp; k < r0 + PLANE; k += 4) {
+						const uint32_t g0 = gbeg[k], n = cstart[k + 1] - cstart[k];
+						for (uint32_t j = g0; j < g0 + n; ++j)
+							if (j != gi) lj_pair(xi, yi, zi, P.x[j], P.y[j], P.z[j], rc2, eps24, sig2, shift6, acc);
+					}
+				}
+			}
+			// the four lanes {jo, jo+16, jo+32, jo+48} hold partial forces of the same molecule
+			acc.fx += __shfl_xor(acc.fx, 16);
+			acc.fy += __shfl_xor(acc.fy, 16);
+			acc.fz += __shfl_xor(acc.fz, 16);
+			acc.fx += __shfl_xor(acc.fx, 32);
+			acc.fy += __shfl_xor(acc.fy, 32);
+			acc.fz += __shfl_xor(acc.fz, 32);
+			if (valid && grp == 0) {
+				P.Fx[gi] = acc.fx;
+				P.Fy[gi] = acc.fy;
+				P.Fz[gi] = acc.fz;
+			}
+			u6_tot += acc.u6;
+			vir_tot += acc.vir;
+		}
+	}
+	double u = wave_sum_lj(0.5 * u6_tot), v = wave_sum_lj(0.5 * vir_tot);
+	if (lane == 0) {
+		red[wv][0] = u;
+		red[wv][1] = v;
+	}
+	__syncthreads();
+	if (tid == 0) {
+		double* out = P.partials + (size_t)blockIdx.x * 4;
+		double su = 0., sv = 0.;
+		for (int i = 0; i < NW; ++i) {
+			su += red[i][0];
+			sv += red[i][1];
+		}
+		out[0] = su;
+		out[1] = 0.;
+		out[2] = 0.;
+		out[3] = sv;
+	}
+}
+
+template <int NT, int BY, int BZ, int CAPJ, int ROWS>
+static bool launch_mfma(const ForceParams& p, hipStream_t s, uint32_t* nblocks, size_t partials_cap) {
+	const Grid& g = p.g;
+	const int nbx = g.box[0], nby = (g.box[1] + BY - 1) / BY, nbz = (g.box[2] + BZ - 1) / BZ;
+	const long nb = 8 * (((long)nbx * nby * nbz + 7) / 8);
+	if (nb <= 0 || (size_t)nb > partials_cap || nb > 0x7fffffffL) return false;
+	*nblocks = (uint32_t)nb;
+	hipLaunchKernelGGL((k_force_lj_mfma<NT, BY, BZ, CAPJ, ROWS>), dim3((uint32_t)nb), dim3(NT), 0, s, p, nbx, nby, nbz);
+	return true;
+}
+
 template <int HW, int BX, int BY, int BZ, int CAPJ, int CAPL, int SPLIT>
 static bool launch_brick(const ForceParams& p, hipStream_t s, uint32_t* nblocks, size_t partials_cap) {
 	const Grid& g = p.g;
@@ -382,6 +692,8 @@ static bool launch_brick(const ForceParams& p, hipStream_t s, uint32_t* nblocks,
 bool launch_force_lj(const ForceParams& p, hipStream_t s, uint32_t* nblocks, double* partials, size_t partials_cap,
 					 int split) {
 	(void)partials;
+	if (p.g.hw == 1 && split == 4) return launch_mfma<512, 4, 4, 1400, 32>(p, s, nblocks, partials_cap);
+	if (p.g.hw == 1 && split == 5) return launch_mfma<256, 4, 4, 1976, 32>(p, s, nblocks, partials_cap);
 	if (p.g.hw == 1) {
 		if (split == 2) return launch_brick<1, 4, 2, 2, 1616, 38, 2>(p, s, nblocks, partials_cap);
 		return launch_brick<1, 4, 2, 2, 1656, 71, 1>(p, s, nblocks, partials_cap);

@@ -180,7 +180,7 @@ extern "C" int ls1hip_set_option(ls1hip_ctx* c, const char* name, long v) {
 	} else if (n == "count_pairs") {
 		c->opt_count_pairs = v ? 1 : 0;
 	} else if (n == "lj_split") {
-		REQUIRE(c, v == 1 || v == 2 || v == 4 || v == 5, "lj_split must be 1, 2, 4 or 5 (4/5 = MFMA distance-tile pre-filter, 512/256 threads)");
+		REQUIRE(c, v == 0 || v == 1 || v == 2 || v == 4 || v == 5 || v == 6, "lj_split must be 0 (auto), 1, 2 (list kernel lanes per molecule), 4, 5 or 6 (MFMA pre-filter variants)");
 		c->opt_lj_split = v;
 	} else {
 		FAIL(c, LS1HIP_EINVAL, "unknown option '%s'", name);
@@ -688,7 +688,9 @@ static int launch_forces(ls1hip_ctx* c, int which) {
 	if (which == 0 || which == 1) launch_clear_macro(c->d_cnt, c->stream);
 	bool done = false;
 	if (c->one_clj && c->opt_force_kernel != LS1HIP_FK_GENERIC && !c->opt_vi && !c->opt_count_pairs) {
-		done = launch_force_lj(P, c->stream, &nblocks, c->d_partials, c->partials_cap, (int)c->opt_lj_split);
+		const double ncell = (double)c->g.box[0] * c->g.box[1] * c->g.box[2];
+		done = launch_force_lj(P, c->stream, &nblocks, c->d_partials, c->partials_cap, (int)c->opt_lj_split,
+							   ncell > 0 ? (double)c->n_real / ncell : 0.);
 	}
 	if (!done) {
 		if (c->opt_force_kernel == LS1HIP_FK_LDS_LIST && !c->one_clj)

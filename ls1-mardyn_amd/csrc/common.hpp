@@ -85,7 +85,7 @@ struct ls1hip_ctx {
 	hipStream_t stream = nullptr;
 	std::string err;
 	// options
-	long opt_force_kernel = LS1HIP_FK_AUTO, opt_cic = 1, opt_vi = 0, opt_det = 1, opt_count_pairs = 0, opt_lj_split = 2;
+	long opt_force_kernel = LS1HIP_FK_AUTO, opt_cic = 1, opt_vi = 0, opt_det = 1, opt_count_pairs = 0, opt_lj_split = 0;
 	// model
 	bool have_comp = false, have_domain = false;
 	ls1::CompTable h_ct;
@@ -180,7 +180,7 @@ void launch_pack_copy(double* dst, const double* src, uint32_t ndoubles, hipStre
 void launch_force_generic(const ForceParams& p, bool one_clj, bool with_vi, bool has_rot, hipStream_t s, uint32_t* nblocks);
 // LDS-tiled 1CLJ kernel (kernels_force_lj.hip); returns false if it cannot handle the configuration
 bool launch_force_lj(const ForceParams& p, hipStream_t s, uint32_t* nblocks, double* partials, size_t partials_cap,
-					 int split);
+					 int split, double mean_per_cell);
 void launch_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, double* stage, hipStream_t s);
 void launch_clear_macro(DevCounters* cnt, hipStream_t s);
 

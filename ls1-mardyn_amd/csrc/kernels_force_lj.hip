@@ -384,8 +384,8 @@ __global__ void __launch_bounds__(LTPB * SPLIT, 2 * SPLIT) k_force_lj_brick(Forc
 // Owned tile = the molecules of one cell (padded to 16); pencil bricks (1 x BY x BZ cells) make the 9 neighbour cells
 // of every z-plane ONE contiguous LDS range, so a cell has 3 candidate ranges of ~112 molecules = 7 tiles each.
 //
-// LDS: only FP64 data is staged (x, y, z absolute and |r_rel|^2, 32 B per molecule); the A operand is converted on
-// load ((float)(s4[k][i] - origin_k), 2 VALU per tile).  List entries are BYTE offsets (8 * index, u16) so phase 2 uses
+// LDS: x, y, z are staged once, in FP64 (absolute), plus the FP32 |r_rel|^2: 28 B per molecule; the A operand is
+// converted on load ((float)(x_k[i] - origin_k), 3 VALU per tile).  List entries are BYTE offsets (8 * index, u16) so phase 2 uses
 // them as LDS addresses directly.  The append is an unconditional store to slot `cnt` followed by cnt += hit
 // (v_cmp + v_addc): a miss is overwritten by the next store; cnt is clamped once per tile, which costs 4 spare rows.
 // ======================================================================================================================
@@ -428,7 +428,12 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 	static_assert(NBC % NW == 0, "cells must divide evenly over the waves");
 	static_assert(NRC <= NT * 4, "region too large for the block scan");
 	static_assert(CAPS * 8 <= 65536, "list entries are u16 byte offsets");
-	__shared__ double s4[4][CAPS];           // x, y, z (absolute) and |r_rel|^2 of every staged molecule
+	// staged molecules: x, y, z absolute (FP64, three arrays of CAPS) followed by |r_rel|^2 (FP32, CAPS): 28 B / molecule
+	__shared__ __attribute__((aligned(16))) char sraw[CAPS * 28 + 8];
+	double* const sx = reinterpret_cast<double*>(sraw);
+	double* const sy = sx + CAPS;
+	double* const sz = sy + CAPS;
+	float* const sq = reinterpret_cast<float*>(sz + CAPS);
 	__shared__ uint16_t lst[ROWS * NT];      // per-lane candidate lists, slot-major
 	__shared__ uint32_t cstart[NRC + 1];
 	__shared__ uint32_t gbeg[NRC];
@@ -489,16 +494,16 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 				}
 				const uint32_t g = gbeg[lo] + (s - cstart[lo]);
 				const double x = P.x[g], y = P.y[g], z = P.z[g];
-				s4[0][s] = x;
-				s4[1][s] = y;
-				s4[2][s] = z;
+				sx[s] = x;
+				sy[s] = y;
+				sz[s] = z;
 				const float fx = (float)(x - ox), fy = (float)(y - oy), fz = (float)(z - oz);
-				s4[3][s] = (double)(fx * fx + fy * fy + fz * fz);
+				sq[s] = fx * fx + fy * fy + fz * fz;
 			} else {  // padding behind the last molecule: far away, never within the cutoff
-				s4[0][s] = ox;
-				s4[1][s] = oy;
-				s4[2][s] = oz;
-				s4[3][s] = 3.0e30;
+				sx[s] = ox;
+				sy[s] = oy;
+				sz[s] = oz;
+				sq[s] = 3.0e30f;
 			}
 		}
 	}
@@ -513,11 +518,19 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 	const int jo = lane & 15, grp = lane >> 4;
 	const uint32_t lane_off = (uint32_t)tid * 2u;
 	char* const lst_bytes = reinterpret_cast<char*>(lst);
-	const char* const sxb = reinterpret_cast<const char*>(&s4[0][0]);
-	const char* const syb = reinterpret_cast<const char*>(&s4[1][0]);
-	const char* const szb = reinterpret_cast<const char*>(&s4[2][0]);
+	const char* const sxb = reinterpret_cast<const char*>(sx);
+	const char* const syb = reinterpret_cast<const char*>(sy);
+	const char* const szb = reinterpret_cast<const char*>(sz);
 	const double o_l = (grp == 0) ? ox : (grp == 1) ? oy : (grp == 2) ? oz : 0.0;  // origin of this lane's A component
-	const double* const arow = &s4[grp][jo];
+	// this lane's A component as a strided byte stream: FP64 coordinates for k = 0..2, the FP32 |r|^2 for k = 3.  Both
+	// are fetched with the same two-dword LDS read (4-byte aligned), the k = 3 lanes use the low dword as is.
+	const uint32_t astride = (grp == 3) ? 4u : 8u;
+	const char* const arow = sraw + (size_t)grp * CAPS * 8 + (size_t)jo * astride;
+	auto load_a = [&](const char* pa) -> float {
+		const uint32_t lo = reinterpret_cast<const uint32_t*>(pa)[0], hi = reinterpret_cast<const uint32_t*>(pa)[1];
+		const float conv = (float)(__hiloint2double((int)hi, (int)lo) - o_l);
+		return (grp == 3) ? __uint_as_float(lo) : conv;
+	};
 	double u6_tot = 0., vir_tot = 0.;
 
 	for (int cc = 0; cc < NBC / NW; ++cc) {              // every wave owns NBC/NW cells of the brick
@@ -537,9 +550,9 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 				float bval = (grp < 3) ? 0.f : 1.f;
 				float thr = -3.0e38f;
 				if (valid) {
-					const float own = (float)(s4[grp][oi] - o_l);
+					const float own = (float)(sx[(grp < 3 ? grp : 0) * CAPS + oi] - o_l);
 					bval = (grp < 3) ? -2.f * own : 1.f;
-					thr = rc2m - (float)s4[3][oi];
+					thr = rc2m - sq[oi];
 				}
 				uint32_t cnt = 0;
 				// ---- phase 1: MFMA distance tiles -> per-lane lists --------------------------------------------------
@@ -549,14 +562,14 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 					const uint32_t jb = (uint32_t)__builtin_amdgcn_readfirstlane((int)cstart[r0]);
 					const uint32_t je = (uint32_t)__builtin_amdgcn_readfirstlane((int)cstart[r0 + PLANE]);
 					if (jb >= je) continue;  // wave-uniform
-					const double* ap = arow + jb;
+					const char* ap = arow + jb * astride;
 					uint32_t cb8 = (jb + 4u * (uint32_t)grp) * 8u;  // byte offset of this lane's first candidate of the tile
-					double a_next = ap[0];
+					float a_next = load_a(ap);
 					uint32_t t = jb;
 					for (; t + 16u < je; t += 16u) {  // full tiles: every candidate is real, no bound test
-						const float a = (float)(a_next - o_l);
-						ap += 16;
-						a_next = ap[0];
+						const float a = a_next;
+						ap += 16u * astride;
+						a_next = load_a(ap);
 						const floatx4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bval, zero, 0, 0, 0);
 #pragma unroll
 						for (int r = 0; r < 4; ++r) {
@@ -567,7 +580,7 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 						cb8 += 128u;
 					}
 					{  // last (partial) tile of the range
-						const float a = (float)(a_next - o_l);
+						const float a = a_next;
 						const floatx4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bval, zero, 0, 0, 0);
 						const uint32_t je8 = je * 8u;
 #pragma unroll
@@ -581,7 +594,7 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 				}
 				// ---- phase 2: exact FP64 evaluation of the listed pairs (strict mask; self pair has r2 == 0) --------
 				if (valid) {
-					const double xi = s4[0][oi], yi = s4[1][oi], zi = s4[2][oi];
+					const double xi = sx[oi], yi = sy[oi], zi = sz[oi];
 					if (cnt < CAPX) {
 						double slj = 0.;
 						uint32_t nin = 0;
@@ -613,7 +626,7 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 							for (uint32_t t = jb; t < je; t += 16)
 								for (uint32_t r = 0; r < 4; ++r) {
 									const uint32_t j = t + 4u * (uint32_t)grp + r;
-									if (j < je) lj_pair(xi, yi, zi, s4[0][j], s4[1][j], s4[2][j], rc2, eps24, sig2, shift6, acc);
+									if (j < je) lj_pair(xi, yi, zi, sx[j], sy[j], sz[j], rc2, eps24, sig2, shift6, acc);
 								}
 						}
 					}
@@ -689,17 +702,30 @@ static bool launch_brick(const ForceParams& p, hipStream_t s, uint32_t* nblocks,
 	return true;
 }
 
+// `split` selects the variant (option "lj_split"): 1 / 2 = list kernel with that many lanes per molecule,
+// 4 = MFMA pre-filter kernel, 1x4x4-cell bricks, 512 threads; 5 = same with 256 threads (larger staging area);
+// 6 = MFMA kernel with 1x4x2-cell bricks (denser systems); 0 = choose from the mean cell occupancy.
 bool launch_force_lj(const ForceParams& p, hipStream_t s, uint32_t* nblocks, double* partials, size_t partials_cap,
-					 int split) {
+					 int split, double mean_per_cell) {
 	(void)partials;
-	if (p.g.hw == 1 && split == 4) return launch_mfma<512, 4, 4, 1400, 32>(p, s, nblocks, partials_cap);
-	if (p.g.hw == 1 && split == 5) return launch_mfma<256, 4, 4, 1976, 32>(p, s, nblocks, partials_cap);
+	if (split == 0) {
+		// staging capacity with 8 % headroom for density fluctuations; a brick that still overflows falls back (slowly)
+		// to global memory inside the kernel, so the choice only affects speed
+		split = 2;
+		if (p.g.hw == 1) {
+			if (mean_per_cell * 108. * 1.08 <= 1680.) split = 4;
+			else if (mean_per_cell * 72. * 1.08 <= 1680.) split = 6;
+		}
+	}
 	if (p.g.hw == 1) {
+		if (split == 4) return launch_mfma<512, 4, 4, 1680, 32>(p, s, nblocks, partials_cap);
+		if (split == 5) return launch_mfma<256, 4, 4, 2264, 32>(p, s, nblocks, partials_cap);
+		if (split == 6) return launch_mfma<512, 4, 2, 1680, 32>(p, s, nblocks, partials_cap);
 		if (split == 2) return launch_brick<1, 4, 2, 2, 1616, 38, 2>(p, s, nblocks, partials_cap);
 		return launch_brick<1, 4, 2, 2, 1656, 71, 1>(p, s, nblocks, partials_cap);
 	}
 	if (p.g.hw == 2) {
-		if (split == 2) return launch_brick<2, 8, 4, 4, 1440, 38, 2>(p, s, nblocks, partials_cap);
+		if (split == 2 || split >= 4) return launch_brick<2, 8, 4, 4, 1440, 38, 2>(p, s, nblocks, partials_cap);
 		return launch_brick<2, 8, 4, 4, 1528, 63, 1>(p, s, nblocks, partials_cap);
 	}
 	return false;

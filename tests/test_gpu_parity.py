@@ -324,7 +324,7 @@ def test_seam_a_soa_forces_matches_reference():
 LJ1_CASES = ["U0", "F0", "U0_periodic", "lj1clj", "bcc1clj_3456", "bcc1clj_16000"]
 
 
-@pytest.mark.parametrize("split", [1, 2, 4, 5])
+@pytest.mark.parametrize("split", [0, 1, 2, 4, 5, 6])
 @pytest.mark.parametrize("cic", [1, 2])
 @pytest.mark.parametrize("name", LJ1_CASES)
 def test_lds_kernel_matches_reference_golden(name, cic, split):
@@ -353,7 +353,7 @@ def test_lds_kernel_equals_generic_kernel_large_box():
                         r, v, np.tile([1., 0, 0, 0], (N, 1)), np.zeros((N, 3)))
     st = sorted_phase_space(ps)
     gen = run_forces(ps, st, 2.5, True, kernel=capi.FK_GENERIC, vi=False)
-    for cic, split in ((1, 1), (1, 2), (1, 4), (1, 5), (2, 1), (2, 2)):
+    for cic, split in ((1, 1), (1, 2), (1, 4), (1, 5), (1, 6), (1, 0), (2, 1), (2, 2)):
         lds = run_forces(ps, st, 2.5, True, kernel=capi.FK_LDS_LIST, vi=False, cic=cic, split=split)
         assert rel_max(lds["F"], gen["F"]) < 1e-13
         assert abs(lds["upot"] - gen["upot"]) < 1e-12 * abs(gen["upot"])
@@ -383,7 +383,7 @@ def test_lds_kernel_dense_cluster_fallbacks():
                         r, np.zeros((N, 3)), np.tile([1., 0, 0, 0], (N, 1)), np.zeros((N, 3)))
     st = sorted_phase_space(ps)
     gen = run_forces(ps, st, 2.5, True, kernel=capi.FK_GENERIC, vi=False)
-    for split in (1, 2, 4, 5):
+    for split in (0, 1, 2, 4, 5, 6):
         lds = run_forces(ps, st, 2.5, True, kernel=capi.FK_LDS_LIST, vi=False, split=split)
         assert rel_max(lds["F"], gen["F"]) < 1e-12
         assert abs(lds["upot"] - gen["upot"]) < 1e-12 * abs(gen["upot"])

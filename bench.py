@@ -223,10 +223,11 @@ def main():
     # offline on this exact workload and committed under profiles/ (PMC collection cannot run inside the timed loop)
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_c_pmc_summary.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r1_d_pmc_summary.json")) as fh:
             pm = json.load(fh)["force_kernel"]
         if world == 1 and abs(pm["algorithmic_bytes_per_launch"] - FORCE_BYTES_PER_MOLECULE * n_local) < 1 and \
-                e.get_option("cells_in_cutoff") == 1 and e.get_option("force_kernel") in (0, 2):
+                e.get_option("cells_in_cutoff") == 1 and e.get_option("force_kernel") in (0, 2) and \
+                e.get_option("lj_split") == 0:
             traffic = pm["traffic_bytes_per_launch"]
     except Exception:
         traffic = None

@@ -65,7 +65,14 @@ const char* ls1hip_version(void);
 
 /* Integer options: "force_kernel" (LS1HIP_FK_*), "cells_in_cutoff" (1|2, LinkedCells <cellsInCutoffRadius>,
  * particleContainer/LinkedCells.h:81-106), "compute_vi" (0|1 per-molecule virial Vi output),
- * "deterministic" (0|1 canonical in-cell order by molecule id). */
+ * "deterministic" (0|1 canonical in-cell order by molecule id),
+ * "count_pairs" (0|1 tally molecule pairs / site interactions inside the cutoff for ls1hip_pair_stats — the
+ * counters of adapter/FlopCounter.cpp:20-76; forces then use the generic kernel),
+ * "lj_split" (variant of the single-centre LJ fast path; results are the same to rounding, only speed differs:
+ *   0 = choose from the mean cell occupancy (default); 1 | 2 = list kernel with 1 | 2 lanes per molecule;
+ *   4 = FP32 MFMA distance-tile pre-filter + exact FP64 evaluation, 1x4x4-cell bricks, 512 threads;
+ *   5 = the same with 256 threads (larger staging area); 6 = 1x4x2-cell bricks (dense cells).
+ *   4-6 need cells_in_cutoff = 1 and fall back to the list kernel otherwise). */
 int ls1hip_set_option(ls1hip_ctx* ctx, const char* name, long value);
 int ls1hip_get_option(const ls1hip_ctx* ctx, const char* name, long* value);
 

@@ -1,0 +1,66 @@
+"""Condenses the rocprofv3 outputs of tools/collect_profiles.sh into kernel_stats.csv + pmc_summary.json.
+
+Corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE are
+reported in KB; on gfx950 FETCH_SIZE counts half of the bytes for 8 B/lane coalesced reads (calibrated here on
+k_kick_then_kick_drift, whose traffic is known exactly: 72 B read, 48 B written per molecule)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+out = sys.argv[1]
+bench_args = sys.argv[2:]
+stats = glob.glob(os.path.join(out, "stats", "*", "*kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], os.path.join(out, "kernel_stats.csv"))
+per = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(out, "pmc_*", "*", "*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        per[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+kern = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in per.items()}
+bench = json.loads(open(os.path.join(out, "bench_under_profiler.json")).read().strip().splitlines()[-1])
+n = bench["config"]["molecules_per_gpu"]
+summary = {"source": "tools/collect_profiles.sh (rocprofv3 --pmc, one pass per counter group, --kernel-trace only), "
+                     "bench.py " + " ".join(bench_args) + ", per-launch means",
+           "units": {"FETCH_SIZE": "KB as reported", "WRITE_SIZE": "KB as reported", "SQ_*_CYCLES": "quad-cycles"},
+           "molecules": n, "kernels": kern}
+kd = [k for k in kern if "k_kick_then_kick_drift" in k]
+if kd and "FETCH_SIZE" in kern[kd[0]]:
+    k = kern[kd[0]]
+    summary["calibration"] = {"kernel": kd[0], "known_read_bytes": 72.0 * n, "known_write_bytes": 48.0 * n,
+                              "FETCH_SIZE_bytes_raw": k["FETCH_SIZE"] * 1024, "WRITE_SIZE_bytes_raw": k["WRITE_SIZE"] * 1024,
+                              "fetch_correction": 72.0 * n / (k["FETCH_SIZE"] * 1024)}
+fk = [k for k in kern if "k_force_" in k and "reduce" not in k]
+if fk:
+    k = kern[fk[0]]
+    alg = bench["roofline"]["algorithmic_bytes_per_launch"]
+    fs = {"name": fk[0], "algorithmic_bytes_per_launch": alg}
+    if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+        fs["fetch_bytes_corrected"] = 2.0 * k["FETCH_SIZE"] * 1024
+        fs["write_bytes"] = k["WRITE_SIZE"] * 1024
+        fs["traffic_bytes_per_launch"] = fs["fetch_bytes_corrected"] + fs["write_bytes"]
+    if "TCC_HIT_sum" in k:
+        fs["l2_hit_rate"] = k["TCC_HIT_sum"] / max(k["TCC_HIT_sum"] + k["TCC_MISS_sum"], 1.0)
+    if "GRBM_GUI_ACTIVE" in k:
+        cyc = k["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+        fs["kernel_cycles"] = cyc
+        if "SQ_ACTIVE_INST_VALU" in k:
+            fs["valu_busy_frac_per_simd"] = k["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in k:
+            fs["mfma_busy_frac"] = k["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc)
+        if "SQ_LDS_IDX_ACTIVE" in k:
+            fs["lds_busy_frac_per_cu"] = k["SQ_LDS_IDX_ACTIVE"] / (256.0 * cyc)
+            fs["lds_bank_conflict_frac"] = k["SQ_LDS_BANK_CONFLICT"] / max(k["SQ_LDS_IDX_ACTIVE"], 1.0)
+    if "SQ_INSTS_VALU" in k:
+        fs["valu_wave_insts_per_launch"] = k["SQ_INSTS_VALU"]
+        fs["valu_lane_insts_per_molecule"] = k["SQ_INSTS_VALU"] * 64.0 / n
+        f64 = sum(k.get(c, 0.0) for c in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64"))
+        fs["fp64_arith_share_of_valu"] = f64 / k["SQ_INSTS_VALU"]
+    summary["force_kernel"] = fs
+json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+print(json.dumps(summary.get("force_kernel", {}), indent=1))
+print(json.dumps(summary.get("calibration", {}), indent=1))

@@ -386,23 +386,6 @@ __device__ __forceinline__ void halo_stage_write(const HaloArgs& a, uint32_t slo
 	a.hs.key[slot] = key;
 }
 
-// number of local periodic images of a molecule with near-face flags lo/hi
-__device__ __forceinline__ uint32_t halo_count_local(const HaloArgs& a, const bool lo[3], const bool hi[3]) {
-	uint32_t nloc = 0;
-	for (int sz = -1; sz <= 1; ++sz) {
-		if (!(sz == 0 || (sz < 0 ? lo[2] : hi[2]))) continue;
-		for (int sy = -1; sy <= 1; ++sy) {
-			if (!(sy == 0 || (sy < 0 ? lo[1] : hi[1]))) continue;
-			for (int sx = -1; sx <= 1; ++sx) {
-				if (!(sx == 0 || (sx < 0 ? lo[0] : hi[0]))) continue;
-				if (sx == 0 && sy == 0 && sz == 0) continue;
-				nloc += (a.nbr[(sz + 1) * 9 + (sy + 1) * 3 + (sx + 1)] == a.my_rank) ? 1u : 0u;
-			}
-		}
-	}
-	return nloc;
-}
-
 __device__ __forceinline__ bool halo_flags(const HaloArgs& a, const double r[3], bool lo[3], bool hi[3]) {
 	bool any = false;
 	for (int d = 0; d < 3; ++d) {
@@ -413,9 +396,26 @@ __device__ __forceinline__ bool halo_flags(const HaloArgs& a, const double r[3],
 	return any;
 }
 
-// emit all images of molecule p; local images go to staging slots my_slot, my_slot+1, ...
-__device__ __forceinline__ void halo_emit(const HaloArgs& a, uint32_t p, const double r[3], const bool lo[3],
-										  const bool hi[3], uint32_t& my_slot) {
+// calls f(dir) for every direction in which a molecule with near-face flags lo/hi has an image (open sides skipped)
+template <class F>
+__device__ __forceinline__ void halo_for_each_image(const HaloArgs& a, const bool lo[3], const bool hi[3], F&& f) {
+	for (int sz = -1; sz <= 1; ++sz) {
+		if (!(sz == 0 || (sz < 0 ? lo[2] : hi[2]))) continue;
+		for (int sy = -1; sy <= 1; ++sy) {
+			if (!(sy == 0 || (sy < 0 ? lo[1] : hi[1]))) continue;
+			for (int sx = -1; sx <= 1; ++sx) {
+				if (!(sx == 0 || (sx < 0 ? lo[0] : hi[0]))) continue;
+				if (sx == 0 && sy == 0 && sz == 0) continue;
+				const int dir = (sz + 1) * 9 + (sy + 1) * 3 + (sx + 1);
+				if (a.nbr[dir] < 0) continue;  // open boundary: no image from that side
+				f(dir);
+			}
+		}
+	}
+}
+
+// write the image of molecule p in direction dir to slot `slot` of its destination (local staging or export buffer)
+__device__ __forceinline__ void halo_emit(const HaloArgs& a, uint32_t p, const double r[3], int dir, uint32_t slot) {
 	const uint64_t id = a.mol.id[p];
 	const int32_t cid = a.mol.cid[p];
 	double q0 = 1., q1 = 0., q2 = 0., q3 = 0.;
@@ -425,101 +425,123 @@ __device__ __forceinline__ void halo_emit(const HaloArgs& a, uint32_t p, const d
 		q2 = a.mol.q2[p];
 		q3 = a.mol.q3[p];
 	}
-	for (int sz = -1; sz <= 1; ++sz) {
-		if (!(sz == 0 || (sz < 0 ? lo[2] : hi[2]))) continue;
-		for (int sy = -1; sy <= 1; ++sy) {
-			if (!(sy == 0 || (sy < 0 ? lo[1] : hi[1]))) continue;
-			for (int sx = -1; sx <= 1; ++sx) {
-				if (!(sx == 0 || (sx < 0 ? lo[0] : hi[0]))) continue;
-				if (sx == 0 && sy == 0 && sz == 0) continue;
-				const int dir = (sz + 1) * 9 + (sy + 1) * 3 + (sx + 1);
-				const int dest = a.nbr[dir];
-				if (dest < 0) continue;  // open boundary: no image from that side
-				double rn[3];
-				for (int d = 0; d < 3; ++d) rn[d] = r[d] + a.shift[dir][d];
-				if (dest == a.my_rank) {
-					// rounding guards of populateHaloLayerWithCopies (DomainDecompBase.cpp:330-343)
-					for (int d = 0; d < 3; ++d) {
-						const double sh = a.shift[dir][d];
-						if (sh < 0.) {
-							if (rn[d] >= a.g.bmin[d]) rn[d] = next_toward_down(a.g.bmin[d]);
-						} else if (sh > 0.) {
-							if (rn[d] < a.g.bmax[d]) rn[d] = next_toward_up(a.g.bmax[d]);
-						}
-					}
-					const uint32_t slot = my_slot++;
-					if (slot >= a.cap_halo) {
-						atomicAdd(&a.cnt->err_overflow, 1u);
-						continue;
-					}
-					halo_stage_write(a, slot, rn, id, cid, q0, q1, q2, q3);
-				} else {
-					const uint32_t slot = atomicAdd(&a.cnt->exp_halo[dir], 1u);
-					const uint32_t cap = a.exp_off[dir + 1] - a.exp_off[dir];
-					if (slot >= cap) {
-						atomicAdd(&a.cnt->err_overflow, 1u);
-						continue;
-					}
-					double* rec = a.exp_halo + (size_t)(a.exp_off[dir] + slot) * LS1HIP_HALO_DOUBLES;
-					rec[0] = __longlong_as_double((long long)id);
-					rec[1] = __longlong_as_double((long long)cid);
-					rec[2] = rn[0];
-					rec[3] = rn[1];
-					rec[4] = rn[2];
-					rec[5] = q0;
-					rec[6] = q1;
-					rec[7] = q2;
-					rec[8] = q3;
-				}
+	double rn[3];
+	for (int d = 0; d < 3; ++d) rn[d] = r[d] + a.shift[dir][d];
+	if (a.nbr[dir] == a.my_rank) {
+		// rounding guards of populateHaloLayerWithCopies (DomainDecompBase.cpp:330-343)
+		for (int d = 0; d < 3; ++d) {
+			const double sh = a.shift[dir][d];
+			if (sh < 0.) {
+				if (rn[d] >= a.g.bmin[d]) rn[d] = next_toward_down(a.g.bmin[d]);
+			} else if (sh > 0.) {
+				if (rn[d] < a.g.bmax[d]) rn[d] = next_toward_up(a.g.bmax[d]);
 			}
 		}
+		if (slot >= a.cap_halo) {
+			atomicAdd(&a.cnt->err_overflow, 1u);
+			return;
+		}
+		halo_stage_write(a, slot, rn, id, cid, q0, q1, q2, q3);
+	} else {
+		const uint32_t cap = a.exp_off[dir + 1] - a.exp_off[dir];
+		if (slot >= cap) {
+			atomicAdd(&a.cnt->err_overflow, 1u);
+			return;
+		}
+		double* rec = a.exp_halo + (size_t)(a.exp_off[dir] + slot) * LS1HIP_HALO_DOUBLES;
+		rec[0] = __longlong_as_double((long long)id);
+		rec[1] = __longlong_as_double((long long)cid);
+		rec[2] = rn[0];
+		rec[3] = rn[1];
+		rec[4] = rn[2];
+		rec[5] = q0;
+		rec[6] = q1;
+		rec[7] = q2;
+		rec[8] = q3;
 	}
 }
 
-// 16 lanes per SHELL cell (4 cells per wave).  Only cells of the outermost hw layers of owned cells can hold molecules
-// within rc of a face (cell edge >= rc/hw); their indices are listed once per domain (ls1hip_set_domain), so the pass
-// reads ~6 % of the molecules instead of all.  Local images of the whole wave get their staging slots from ONE atomic (a single
-// global counter would otherwise serialise every boundary molecule of the domain).
+// 16 lanes per SHELL cell, HG_ITER cells per lane group, 64 cells per workgroup.  Only cells of the outermost hw layers
+// of owned cells can hold molecules within rc of a face (cell edge >= rc/hw); their indices are listed once per domain
+// (ls1hip_set_domain), so the pass reads ~6 % of the molecules instead of all.
+// Slot allocation: the images of a workgroup are counted per direction in LDS, ONE global atomic per workgroup and
+// destination reserves the range (all local images share one; measured: one same-address global atomic per wave
+// serialised the whole kernel at ~15 ns each = 0.19 ms at 10^7 molecules), then LDS atomics hand out the slots.
+// The order inside a destination buffer is arbitrary; the halo sort (key, rank, id) canonicalises it.
 constexpr int HG_LANES = 16;
+constexpr int HG_ITER = 4;
 __global__ void __launch_bounds__(TPB) k_halo_gen(HaloArgs a) {
-	const uint32_t k = (blockIdx.x * TPB + threadIdx.x) / HG_LANES;  // index into the precomputed shell-cell list
-	const uint32_t sub = threadIdx.x % HG_LANES;
-	uint32_t pb = 0, pe = 0;
-	if (k < a.nshell) {
-		const uint32_t c = a.shell[k];
-		pb = a.cell_begin[c];
-		pe = a.cell_end[c];
+	__shared__ uint32_t s_cnt[27], s_base[27];
+	const int tid = threadIdx.x;
+	if (tid < 27) s_cnt[tid] = 0;
+	__syncthreads();
+	constexpr uint32_t GROUPS = TPB / HG_LANES;
+	const uint32_t k0 = blockIdx.x * (GROUPS * HG_ITER) + (uint32_t)tid / HG_LANES;
+	const uint32_t sub = (uint32_t)tid % HG_LANES;
+	uint32_t pb[HG_ITER], pe[HG_ITER];
+#pragma unroll
+	for (int it = 0; it < HG_ITER; ++it) {
+		const uint32_t k = k0 + (uint32_t)it * GROUPS;
+		pb[it] = pe[it] = 0;
+		if (k < a.nshell) {
+			const uint32_t c = a.shell[k];
+			pb[it] = a.cell_begin[c];
+			pe[it] = a.cell_end[c];
+		}
 	}
-	if (!__any(pe > pb)) return;  // wave-uniform
-	uint32_t nloc = 0;
-	for (uint32_t p = pb + sub; p < pe; p += HG_LANES) {
-		const double r[3] = {a.mol.x[p], a.mol.y[p], a.mol.z[p]};
-		bool lo[3], hi[3];
-		if (halo_flags(a, r, lo, hi)) nloc += halo_count_local(a, lo, hi);
+	// pass 1: count images per direction
+#pragma unroll
+	for (int it = 0; it < HG_ITER; ++it)
+		for (uint32_t p = pb[it] + sub; p < pe[it]; p += HG_LANES) {
+			const double r[3] = {a.mol.x[p], a.mol.y[p], a.mol.z[p]};
+			bool lo[3], hi[3];
+			if (halo_flags(a, r, lo, hi)) halo_for_each_image(a, lo, hi, [&](int dir) { atomicAdd(&s_cnt[dir], 1u); });
+		}
+	__syncthreads();
+	// reserve: remote directions one atomic each (distinct counters), all local images one atomic
+	if (tid < 27) {
+		const int dest = a.nbr[tid];
+		if (tid != 13 && dest >= 0 && dest != a.my_rank && s_cnt[tid]) s_base[tid] = atomicAdd(&a.cnt->exp_halo[tid], s_cnt[tid]);
+	} else if (tid == 64) {
+		uint32_t tot = 0;
+		for (int dir = 0; dir < 27; ++dir)
+			if (dir != 13 && a.nbr[dir] == a.my_rank) tot += s_cnt[dir];
+		uint32_t base = tot ? atomicAdd(&a.cnt->n_halo_staged, tot) : 0u;
+		for (int dir = 0; dir < 27; ++dir)
+			if (dir != 13 && a.nbr[dir] == a.my_rank) {
+				s_base[dir] = base;
+				base += s_cnt[dir];
+			}
 	}
-	uint32_t incl = nloc;
-	const int lane = threadIdx.x & 63;
-	for (int o = 1; o < 64; o <<= 1) {
-		const uint32_t t = __shfl_up(incl, o);
-		if (lane >= o) incl += t;
-	}
-	const uint32_t wave_total = __shfl(incl, 63);
-	uint32_t wave_base = 0;
-	if (lane == 63 && wave_total) wave_base = atomicAdd(&a.cnt->n_halo_staged, wave_total);
-	wave_base = __shfl(wave_base, 63);
-	uint32_t my_slot = wave_base + incl - nloc;
-	for (uint32_t p = pb + sub; p < pe; p += HG_LANES) {
-		const double r[3] = {a.mol.x[p], a.mol.y[p], a.mol.z[p]};
-		bool lo[3], hi[3];
-		if (halo_flags(a, r, lo, hi)) halo_emit(a, p, r, lo, hi, my_slot);
-	}
+	__syncthreads();
+	if (tid < 27) s_cnt[tid] = 0;
+	__syncthreads();
+	// pass 2: emit
+#pragma unroll
+	for (int it = 0; it < HG_ITER; ++it)
+		for (uint32_t p = pb[it] + sub; p < pe[it]; p += HG_LANES) {
+			const double r[3] = {a.mol.x[p], a.mol.y[p], a.mol.z[p]};
+			bool lo[3], hi[3];
+			if (halo_flags(a, r, lo, hi))
+				halo_for_each_image(a, lo, hi, [&](int dir) {
+					const uint32_t slot = s_base[dir] + atomicAdd(&s_cnt[dir], 1u);
+					halo_emit(a, p, r, dir, slot);
+				});
+		}
 }
 
-__global__ void __launch_bounds__(TPB) k_halo_import(HaloArgs a, const double* rec, uint32_t n) {
-	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+// one global atomic per 1024-record workgroup reserves the staging slots (a per-record or per-wave atomic on the single
+// counter serialises at ~15 ns each)
+constexpr int HI_TPB = 1024;
+__global__ void __launch_bounds__(HI_TPB) k_halo_import(HaloArgs a, const double* rec, uint32_t n) {
+	__shared__ uint32_t s_base;
+	const uint32_t first = blockIdx.x * HI_TPB;
+	if (threadIdx.x == 0) s_base = atomicAdd(&a.cnt->n_halo_staged, min((uint32_t)HI_TPB, n - first));
+	__syncthreads();
+	const uint32_t i = first + threadIdx.x;
 	if (i >= n) return;
 	const double* r = rec + (size_t)i * LS1HIP_HALO_DOUBLES;
-	const uint32_t slot = atomicAdd(&a.cnt->n_halo_staged, 1u);
+	const uint32_t slot = s_base + threadIdx.x;
 	if (slot >= a.cap_halo) {
 		atomicAdd(&a.cnt->err_overflow, 1u);
 		return;
@@ -567,12 +589,12 @@ void launch_halo_generate(const HaloArgs& a, hipStream_t s) {
 	hipLaunchKernelGGL(k_zero_halo_counts, dim3((a.g.ncells + TPB - 1) / TPB), dim3(TPB), 0, s, a.g, a.count);
 	if (a.n_real_cap == 0) return;
 	if (a.nshell == 0) return;
-	hipLaunchKernelGGL(k_halo_gen, dim3(((size_t)a.nshell * HG_LANES + TPB - 1) / TPB), dim3(TPB), 0, s, a);
+	hipLaunchKernelGGL(k_halo_gen, dim3(((size_t)a.nshell * HG_LANES + TPB * HG_ITER - 1) / (TPB * HG_ITER)), dim3(TPB), 0, s, a);
 }
 
 void launch_halo_import(const HaloArgs& a, const double* dev_records, uint32_t n, hipStream_t s) {
 	if (n == 0) return;
-	hipLaunchKernelGGL(k_halo_import, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, s, a, dev_records, n);
+	hipLaunchKernelGGL(k_halo_import, dim3((n + HI_TPB - 1) / HI_TPB), dim3(HI_TPB), 0, s, a, dev_records, n);
 }
 
 // clamp n_halo to the capacity (after an overflow the error flag is set; keep indices in range)

@@ -190,8 +190,14 @@ int ls1hip_run(ls1hip_ctx* ctx, double dt, unsigned long nsteps, double* out6);
 int ls1hip_export_counts(ls1hip_ctx* ctx, int kind, uint64_t counts[27]);
 /* Copy the packed records of direction `dir` into the DEVICE buffer dev_buf (capacity in records). */
 int ls1hip_export_pack(ls1hip_ctx* ctx, int kind, int dir, void* dev_buf, size_t cap);
+/* The same for a list of directions, records back to back in the order given: one message per PEER (all directions
+ * that point at the same neighbour rank), one stream synchronisation per message instead of one per direction.
+ * Replaces the per-neighbour send loop of DirectNeighbourCommunicationScheme::initExchangeMoleculesMPI
+ * (parallel/NeighbourCommunicationScheme.cpp:115-136). */
+int ls1hip_export_pack_dirs(ls1hip_ctx* ctx, int kind, const int* dirs, int ndirs, void* dev_buf, size_t cap);
 /* Append `n` received records from DEVICE buffer dev_buf: kind 0 -> owned molecules (then call ls1hip_rebin
- * again is NOT needed: they are binned on arrival), kind 1 -> halo copies.  Call ls1hip_import_done(kind)
+ * again is NOT needed: they are binned on arrival), kind 1 -> halo copies.  The call is asynchronous: dev_buf is read
+ * on the engine's stream and must stay valid until ls1hip_import_done(kind) returns.  Call ls1hip_import_done(kind)
  * after the last import of a kind. */
 int ls1hip_import(ls1hip_ctx* ctx, int kind, const void* dev_buf, size_t n);
 int ls1hip_import_done(ls1hip_ctx* ctx, int kind);

@@ -47,6 +47,7 @@ SYMBOLS = {
     "ls1hip_run": (C.c_int, [C.c_void_p, C.c_double, C.c_ulong, _dp]),
     "ls1hip_export_counts": (C.c_int, [C.c_void_p, C.c_int, _u64p]),
     "ls1hip_export_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    "ls1hip_export_pack_dirs": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_size_t]),
     "ls1hip_import": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "ls1hip_import_done": (C.c_int, [C.c_void_p, C.c_int]),
     "ls1hip_soa_forces": (C.c_int, [C.c_void_p, _ip, _u32p, C.c_size_t, _dp, _dp, _i32p, _dp, _dp, _dp, _dp, _dp]),

@@ -1001,17 +1001,43 @@ extern "C" int ls1hip_export_counts(ls1hip_ctx* c, int kind, uint64_t counts[27]
 	return LS1HIP_OK;
 }
 
-extern "C" int ls1hip_export_pack(ls1hip_ctx* c, int kind, int dir, void* dev_buf, size_t cap) {
-	if (!c) return LS1HIP_EINVAL;
-	REQUIRE(c, (kind == 0 || kind == 1) && dir >= 0 && dir < 27 && dev_buf, "bad argument");
-	HIPCHK(c, hipSetDevice(c->device));
+static int export_pack_async(ls1hip_ctx* c, int kind, int dir, double* dst, size_t cap, uint32_t* n_out) {
 	const uint32_t n = kind == 0 ? c->h_cnt->exp_leave[dir] : c->h_cnt->exp_halo[dir];
 	REQUIRE(c, cap >= n, "export buffer too small: %zu < %u records", cap, n);
 	const int w = kind == 0 ? LS1HIP_LEAVING_DOUBLES : LS1HIP_HALO_DOUBLES;
 	const double* src = kind == 0 ? c->d_exp_leave + (size_t)c->exp_off_leave[dir] * w
 								  : c->d_exp_halo + (size_t)c->exp_off_halo[dir] * w;
-	launch_pack_copy((double*)dev_buf, src, n * w, c->stream);
+	launch_pack_copy(dst, src, n * w, c->stream);
+	*n_out = n;
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_export_pack(ls1hip_ctx* c, int kind, int dir, void* dev_buf, size_t cap) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, (kind == 0 || kind == 1) && dir >= 0 && dir < 27 && dev_buf, "bad argument");
+	HIPCHK(c, hipSetDevice(c->device));
+	uint32_t n = 0;
+	int rc = export_pack_async(c, kind, dir, (double*)dev_buf, cap, &n);
+	if (rc) return rc;
 	HIPCHK(c, hipStreamSynchronize(c->stream));  // the transport runs on its own stream
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_export_pack_dirs(ls1hip_ctx* c, int kind, const int* dirs, int ndirs, void* dev_buf, size_t cap) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, (kind == 0 || kind == 1) && ndirs >= 0 && ndirs <= 27 && (ndirs == 0 || dirs) && (cap == 0 || dev_buf),
+			"bad argument");
+	HIPCHK(c, hipSetDevice(c->device));
+	const int w = kind == 0 ? LS1HIP_LEAVING_DOUBLES : LS1HIP_HALO_DOUBLES;
+	size_t used = 0;
+	for (int k = 0; k < ndirs; ++k) {
+		REQUIRE(c, dirs[k] >= 0 && dirs[k] < 27, "direction %d out of range", dirs[k]);
+		uint32_t n = 0;
+		int rc = export_pack_async(c, kind, dirs[k], (double*)dev_buf + used * w, cap - used, &n);
+		if (rc) return rc;
+		used += n;
+	}
+	HIPCHK(c, hipStreamSynchronize(c->stream));  // one synchronisation per message: the transport runs on its own stream
 	return LS1HIP_OK;
 }
 
@@ -1029,7 +1055,7 @@ extern "C" int ls1hip_import(ls1hip_ctx* c, int kind, const void* dev_buf, size_
 		HaloArgs a = halo_args(c);
 		launch_halo_import(a, (const double*)dev_buf, (uint32_t)n, c->stream);
 	}
-	HIPCHK(c, hipStreamSynchronize(c->stream));  // dev_buf may be reused by the caller
+	// asynchronous: dev_buf is read on the engine's stream and must stay valid until ls1hip_import_done(kind) returns
 	return LS1HIP_OK;
 }
 
@@ -1049,6 +1075,7 @@ extern "C" int ls1hip_import_done(ls1hip_ctx* c, int kind) {
 		HaloArgs a = halo_args(c);
 		launch_halo_finalize(a, c->stream);
 		c->halo_valid = true;
+		HIPCHK(c, hipStreamSynchronize(c->stream));  // imported buffers may be released by the caller from here on
 	}
 	return LS1HIP_OK;
 }

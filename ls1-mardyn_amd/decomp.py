@@ -136,12 +136,7 @@ class HaloExchanger:
             n_in = int(sum(allc[p][d] for d in self._incoming[p]))
             if n_out:
                 buf = torch.empty(n_out * w, dtype=torch.float64, device=self.device)
-                off = 0
-                for d in self._outgoing[p]:
-                    c = int(counts[d])
-                    if c:
-                        self.engine.export_pack(kind, d, self._ptr(buf) + off * w * 8, c)
-                        off += c
+                self.engine.export_pack_dirs(kind, [d for d in self._outgoing[p] if counts[d]], self._ptr(buf), n_out)
                 if self.stage:
                     torch.cuda.synchronize()
                     buf = buf.cpu()
@@ -158,11 +153,14 @@ class HaloExchanger:
             r.wait()
         if self.device.type == "cuda":
             torch.cuda.current_stream().synchronize()
+        keep = []  # imports are asynchronous: the device buffers live until import_done has returned
         for rb, n_in in recv_bufs:
             if self.stage:
                 rb = rb.to(self.device)
+            keep.append(rb)
             self.engine.import_records(kind, self._ptr(rb), n_in)
         self.engine.import_done(kind)
+        del keep
 
 
 class DistributedSimulation:

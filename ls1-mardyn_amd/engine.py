@@ -171,7 +171,13 @@ class DeviceEngine:
     def export_pack(self, kind: int, direction: int, dev_ptr: int, cap: int):
         self._chk(self.lib.ls1hip_export_pack(self.ctx, int(kind), int(direction), C.c_void_p(dev_ptr), int(cap)))
 
+    def export_pack_dirs(self, kind: int, directions, dev_ptr: int, cap: int):
+        """Records of all `directions` back to back (one message per peer, one synchronisation)."""
+        d = (C.c_int * len(directions))(*[int(x) for x in directions])
+        self._chk(self.lib.ls1hip_export_pack_dirs(self.ctx, int(kind), d, len(directions), C.c_void_p(dev_ptr), int(cap)))
+
     def import_records(self, kind: int, dev_ptr: int, n: int):
+        """Asynchronous: the buffer must stay alive until import_done(kind) returns."""
         self._chk(self.lib.ls1hip_import(self.ctx, int(kind), C.c_void_p(dev_ptr), int(n)))
 
     def import_done(self, kind: int):

@@ -103,6 +103,15 @@ class CpuEngine:
         assert cap >= len(rec)
         self._view(ptr, rec.size)[:] = rec.reshape(-1)
 
+    def export_pack_dirs(self, kind, dirs, ptr, cap):
+        w = 15 if kind == 0 else 9
+        off = 0
+        for d in dirs:
+            rec = self.exp[kind][d]
+            assert cap - off >= len(rec)
+            self.export_pack(kind, d, ptr + off * w * 8, cap - off)
+            off += len(rec)
+
     def import_records(self, kind, ptr, n):
         w = 15 if kind == 0 else 9
         rec = self._view(ptr, n * w).reshape(n, w).copy()

@@ -39,13 +39,22 @@ class InProcessCluster:
         bufs = []
         for k, e in enumerate(self.eng):
             nbr = self.dcs[k].neighbor_table()
-            for d in range(27):
-                c = int(counts[k][d])
-                if c and nbr[d] != k:
-                    assert nbr[d] >= 0
-                    t = torch.empty(c * w, dtype=torch.float64, device="cuda:0")
-                    e.export_pack(kind, d, t.data_ptr(), c)
-                    bufs.append((int(nbr[d]), t, c))
+            if k % 2 == 0:  # one message per direction (ls1hip_export_pack)
+                for d in range(27):
+                    c = int(counts[k][d])
+                    if c and nbr[d] != k:
+                        assert nbr[d] >= 0
+                        t = torch.empty(c * w, dtype=torch.float64, device="cuda:0")
+                        e.export_pack(kind, d, t.data_ptr(), c)
+                        bufs.append((int(nbr[d]), t, c))
+            else:  # one message per peer (ls1hip_export_pack_dirs), as decomp.HaloExchanger sends them
+                for peer in sorted({int(p) for p in nbr if p >= 0 and p != k}):
+                    dirs = [d for d in range(27) if d != 13 and nbr[d] == peer and counts[k][d]]
+                    c = int(sum(int(counts[k][d]) for d in dirs))
+                    if c:
+                        t = torch.empty(c * w, dtype=torch.float64, device="cuda:0")
+                        e.export_pack_dirs(kind, dirs, t.data_ptr(), c)
+                        bufs.append((peer, t, c))
         torch.cuda.synchronize()
         for dest, t, c in bufs:
             self.eng[dest].import_records(kind, t.data_ptr(), c)

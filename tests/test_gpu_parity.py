@@ -256,6 +256,57 @@ def test_large_box_properties():
     assert abs(c["virial"] - a["virial"]) < 1e-11 * abs(a["virial"])
 
 
+def test_full_size_properties_bench_workload():
+    """BASELINE configs[1] at FULL size (N = 2*171^3 = 10 000 422, the bench.py workload), through the C ABI:
+    size-independent properties instead of the oracle —
+      * sum F = 0 (Newton 3 through the periodic images) for the shipped MFMA kernel,
+      * MFMA kernel == list kernel == generic kernel on the same state (forces 1e-13, U_pot / virial 1e-12),
+      * inner + boundary traversal == full traversal bit for bit,
+      * 5 NVE steps: total momentum conserved, energy fluctuation |dE|/|E| < 2e-5 (leapfrog, dt = 0.002, jittered-lattice start),
+      * every molecule survives re-binning (ids are a permutation of the input)."""
+    engine_mod = load_pkg("engine")
+    L, r, v = _bcc(171, seed=1)
+    N = len(r)
+    assert N == 10000422
+    comps = inp.ComponentSet([inp.make_component(lj=[(0, 0, 0, 1, 1, 1, 2.5, 0)])], np.zeros((0, 2)), 1e10)
+    eng = engine_mod.DeviceEngine(0)
+    eng.set_components(comps, 2.5)
+    eng.set_domain([L, L, L])
+    eng.upload(np.arange(1, N + 1, dtype=np.uint64), np.zeros(N, np.int32), r, v)
+    eng.rebin(); eng.halo()
+    res = {}
+    for name, fk, split in (("mfma", capi.FK_LDS_LIST, 4), ("list", capi.FK_LDS_LIST, 2), ("generic", capi.FK_GENERIC, 0)):
+        eng.set_option("force_kernel", fk)
+        eng.set_option("lj_split", split)
+        u, w = eng.forces(0)
+        res[name] = (eng.download_forces()["F"], u, w)
+    F, u, w = res["mfma"]
+    Fmax = np.max(np.abs(F))
+    assert np.max(np.abs(F.sum(0))) < 1e-9 * Fmax * np.sqrt(N)
+    for other in ("list", "generic"):
+        Fo, uo, wo = res[other]
+        assert np.max(np.abs(F - Fo)) < 1e-13 * Fmax
+        assert abs(u - uo) < 1e-12 * abs(uo) and abs(w - wo) < 1e-12 * abs(wo)
+    del res
+    eng.set_option("force_kernel", capi.FK_AUTO)
+    eng.set_option("lj_split", 0)
+    eng.forces(1, want_macro=False)
+    u2, w2 = eng.forces(2)
+    assert np.array_equal(eng.download_forces()["F"], F)
+    assert abs(u2 - u) <= 1e-13 * abs(u)
+    # short NVE run from this state
+    ekin0 = 0.5 * float((v * v).sum())
+    out = eng.run(0.002, 5)
+    st = eng.download_state()
+    assert np.array_equal(np.sort(st["ids"]), np.arange(1, N + 1, dtype=np.uint64))
+    p = st["v"].sum(0)
+    assert np.max(np.abs(p)) < 1e-9 * np.sqrt(N)
+    e0 = ekin0 + u
+    e1 = 0.5 * out["summv2"] + out["upot"]
+    assert abs(e1 - e0) < 2e-5 * abs(e0)
+    eng.close()
+
+
 def test_error_conventions():
     ps = inp.read_inp(input_path(MAN["U0"]["input"]))
     st = sorted_phase_space(ps)

@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="force kernel variant (LS1HIP_FK_*)")
     ap.add_argument("--cic", type=int, default=0, help="cells in cutoff (0 = engine default)")
     ap.add_argument("--split", type=int, default=0, help="lanes per molecule in the LDS LJ kernel (0 = engine default)")
+    ap.add_argument("--decomp", action="store_true",
+                    help="diagnostic: run the decomposed (multi-rank) step loop even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -158,8 +160,12 @@ def main():
     inp = importlib.import_module("ls1-mardyn_amd.inp")
     comps = lj_components(inp)
     n = args.n_per_dim
-    if world > 1:
+    if world > 1 or args.decomp:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if rehearse:
             dist.init_process_group("gloo")
         else:

@@ -155,6 +155,11 @@ int ls1hip_forces(ls1hip_ctx* ctx, int which, double* upot, double* virial);
  * v += dt_half/m F; L += dt_half M; returns sum m v^2, sum I w^2, N, rotational DOF (thermostat 0). */
 int ls1hip_kick(ls1hip_ctx* ctx, double dt_half, double* summv2, double* sumIw2, uint64_t* n, uint64_t* rot_dof);
 
+/* eventForcesCalculated of step n immediately followed by eventNewTimestep of step n+1 (Leapfrog.cpp:66-150 then
+ * :48-64) in ONE pass over the molecules: v += dt/m F; r += dt v (and the rotational counterparts) — bitwise the same
+ * as ls1hip_kick(dt/2) + ls1hip_kick_drift(dt), for steps whose kinetic sums are not needed (NVE, no output). */
+int ls1hip_kick_then_kick_drift(ls1hip_ctx* ctx, double dt);
+
 /* VelocityScalingThermostat::apply, global branch (thermostats/VelocityScalingThermostat.cpp:80-96): v *= beta_trans,
  * D *= beta_rot for every owned molecule. */
 int ls1hip_scale_velocities(ls1hip_ctx* ctx, double beta_trans, double beta_rot);

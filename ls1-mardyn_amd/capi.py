@@ -37,6 +37,7 @@ SYMBOLS = {
     "ls1hip_download_state": (C.c_int, [C.c_void_p, C.c_size_t, _u64p, _i32p, _dp, _dp, _dp, _dp]),
     "ls1hip_download_forces": (C.c_int, [C.c_void_p, C.c_size_t, _dp, _dp, _dp]),
     "ls1hip_kick_drift": (C.c_int, [C.c_void_p, C.c_double]),
+    "ls1hip_kick_then_kick_drift": (C.c_int, [C.c_void_p, C.c_double]),
     "ls1hip_rebin": (C.c_int, [C.c_void_p]),
     "ls1hip_halo": (C.c_int, [C.c_void_p]),
     "ls1hip_forces": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp]),
@@ -77,6 +78,14 @@ def load():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise Ls1HipError(-2, f"{LIB_PATH} not found — build it with `make -C {_HERE}`; there is no CPU fallback")
+        # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64.  If libls1hip
+        # pulls in the system runtime first, a later `import torch` initialises a second HSA instance and finds no GPU
+        # ("No HIP GPUs are available").  Loading torch first makes both resolve to the same runtime (same SONAME).
+        # torch is optional for the engine itself (it only supplies device buffers / transports to the callers).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the ABI and the header disagree

@@ -153,6 +153,7 @@ extern "C" int ls1hip_destroy(ls1hip_ctx* c) {
 	hipStreamSynchronize(c->stream);
 	free_mol(c);
 	free_cells(c);
+	for (int k = 0; k < 2; ++k) dfree(c->brick_lists.d[k]);
 	dfree(c->d_ct);
 	dfree(c->d_cnt);
 	dfree(c->d_stage);
@@ -690,7 +691,7 @@ static int launch_forces(ls1hip_ctx* c, int which) {
 	if (c->one_clj && c->opt_force_kernel != LS1HIP_FK_GENERIC && !c->opt_vi && !c->opt_count_pairs) {
 		const double ncell = (double)c->g.box[0] * c->g.box[1] * c->g.box[2];
 		done = launch_force_lj(P, c->stream, &nblocks, c->d_partials, c->partials_cap, (int)c->opt_lj_split,
-							   ncell > 0 ? (double)c->n_real / ncell : 0.);
+							   ncell > 0 ? (double)c->n_real / ncell : 0., &c->brick_lists);
 	}
 	if (!done) {
 		if (c->opt_force_kernel == LS1HIP_FK_LDS_LIST && !c->one_clj)
@@ -747,6 +748,20 @@ extern "C" int ls1hip_kick_drift(ls1hip_ctx* c, double dt) {
 	HIPCHK(c, hipSetDevice(c->device));
 	TimedScope ts(c, c->t_integrate);
 	launch_kick_drift(integ_args(c, dt), c->stream);
+	HIPCHK(c, hipGetLastError());
+	c->binned = false;
+	c->halo_valid = false;
+	c->forces_valid = false;
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_kick_then_kick_drift(ls1hip_ctx* c, double dt) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, c->forces_valid, "forces are not valid (call ls1hip_forces)");
+	REQUIRE(c, !c->thermostat_on, "with the device thermostat the two half kicks are separate passes (kick, scale, kick_drift)");
+	HIPCHK(c, hipSetDevice(c->device));
+	TimedScope ts(c, c->t_integrate);
+	launch_kick_then_kick_drift(integ_args(c, dt), c->stream);
 	HIPCHK(c, hipGetLastError());
 	c->binned = false;
 	c->halo_valid = false;
@@ -895,11 +910,7 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 			if ((rc = ls1hip_kick_drift(c, dt))) return rc;
 		} else {
 			// post-force kick of step s-1 fused with the pre-force kick+drift of step s (same F, one pass)
-			TimedScope ts(c, c->t_integrate);
-			launch_kick_then_kick_drift(integ_args(c, dt), c->stream);
-			c->binned = false;
-			c->halo_valid = false;
-			c->forces_valid = false;
+			if ((rc = ls1hip_kick_then_kick_drift(c, dt))) return rc;
 		}
 		if ((rc = ls1hip_rebin(c)) || (rc = ls1hip_halo(c)) || (rc = ls1hip_forces(c, 0, nullptr, nullptr))) return rc;
 		if (s + 1 == nsteps) {

@@ -67,8 +67,17 @@ struct ForceParams {
 	int which;         // 0 all, 1 inner cells, 2 boundary cells, 3 all non-halo cells (seam A)
 	uint32_t n_fixed;  // if != 0: number of molecules (overrides cnt->n_real; seam A)
 	int count_pairs;
+	const uint32_t* brick_list;  // LJ brick kernels: bricks of this pass (inner / boundary), nullptr = all bricks
+	uint32_t n_list;
 	// 1CLJ fast-path scalars
 	double eps24, sig2, shift6, rc2;
+};
+
+// inner / boundary brick lists of the LJ brick kernels for the current grid and brick shape (kernels_force_lj.hip)
+struct BrickLists {
+	int shape[3] = {0, 0, 0}, dims[3] = {0, 0, 0}, hw = 0;
+	uint32_t* d[2] = {nullptr, nullptr};
+	uint32_t n[2] = {0, 0};
 };
 
 struct Timer {
@@ -86,6 +95,7 @@ struct ls1hip_ctx {
 	std::string err;
 	// options
 	long opt_force_kernel = LS1HIP_FK_AUTO, opt_cic = 1, opt_vi = 0, opt_det = 1, opt_count_pairs = 0, opt_lj_split = 0;
+	ls1::BrickLists brick_lists;
 	// model
 	bool have_comp = false, have_domain = false;
 	ls1::CompTable h_ct;
@@ -180,7 +190,7 @@ void launch_pack_copy(double* dst, const double* src, uint32_t ndoubles, hipStre
 void launch_force_generic(const ForceParams& p, bool one_clj, bool with_vi, bool has_rot, hipStream_t s, uint32_t* nblocks);
 // LDS-tiled 1CLJ kernel (kernels_force_lj.hip); returns false if it cannot handle the configuration
 bool launch_force_lj(const ForceParams& p, hipStream_t s, uint32_t* nblocks, double* partials, size_t partials_cap,
-					 int split, double mean_per_cell);
+					 int split, double mean_per_cell, BrickLists* bl);
 void launch_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, double* stage, hipStream_t s);
 void launch_clear_macro(DevCounters* cnt, hipStream_t s);
 

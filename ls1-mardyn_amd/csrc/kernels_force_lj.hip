@@ -21,6 +21,9 @@
 // own AVX2 path is rcp_ps + 3 Newton steps, RealVecDouble.h:415-434) — parity is tolerance-based (1e-10).
 #include "common.hpp"
 
+#include <algorithm>
+#include <vector>
+
 namespace ls1 {
 
 constexpr int LTPB = 256;
@@ -143,10 +146,13 @@ __global__ void __launch_bounds__(LTPB * SPLIT, 2 * SPLIT) k_force_lj_brick(Forc
 	const int tid = threadIdx.x;
 	// XCD-aware brick order: workgroups are dealt round-robin to the 8 XCDs, so give every XCD a contiguous run of
 	// bricks (neighbouring bricks share most of their shell -> they hit the same 4 MB L2).
-	const int nb = nbx * nby * nbz;
+	// With a brick list (inner / boundary traversal) only the listed bricks are launched: an empty 512-thread, 80 KB
+	// workgroup still costs ~20 ns of dispatch, which made the boundary pass (18 % of the bricks) 2x too slow.
+	const int nb = P.brick_list ? (int)P.n_list : nbx * nby * nbz;
 	const int chunk = gridDim.x / 8;  // the grid is 8 * ceil(nb / 8) workgroups
-	const int brick = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
-	bool live = brick < nb;
+	const int slot = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
+	bool live = slot < nb;
+	const int brick = (live && P.brick_list) ? (int)P.brick_list[slot] : slot;
 	int bx = 0, by = 0, bz = 0;
 	if (live) {
 		bx = brick % nbx;
@@ -156,7 +162,7 @@ __global__ void __launch_bounds__(LTPB * SPLIT, 2 * SPLIT) k_force_lj_brick(Forc
 	// brick origin in grid cell coordinates and its extent (edge bricks are partial)
 	const int x0 = HW + bx * BX, y0 = HW + by * BY, z0 = HW + bz * BZ;
 	const int ex = min(BX, P.g.dims[0] - HW - x0), ey = min(BY, P.g.dims[1] - HW - y0), ez = min(BZ, P.g.dims[2] - HW - z0);
-	if (live && P.which != 0) {
+	if (live && P.which != 0 && !P.brick_list) {
 		// "inner" brick: no halo cell inside its shell (cells [2hw, dims-2hw) in every dimension)
 		const bool inner = x0 >= 2 * HW && y0 >= 2 * HW && z0 >= 2 * HW && x0 + ex <= P.g.dims[0] - 2 * HW &&
 						   y0 + ey <= P.g.dims[1] - 2 * HW && z0 + ez <= P.g.dims[2] - 2 * HW;
@@ -441,10 +447,11 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 	__shared__ double red[NW][2];
 
 	const int tid = threadIdx.x;
-	const int nb = nbx * nby * nbz;
+	const int nb = P.brick_list ? (int)P.n_list : nbx * nby * nbz;
 	const int chunk = gridDim.x / 8;
-	const int brick = (blockIdx.x % 8) * chunk + blockIdx.x / 8;  // XCD-aware brick order (see k_force_lj_brick)
-	bool live = brick < nb;
+	const int slot = (blockIdx.x % 8) * chunk + blockIdx.x / 8;  // XCD-aware brick order (see k_force_lj_brick)
+	bool live = slot < nb;
+	const int brick = (live && P.brick_list) ? (int)P.brick_list[slot] : slot;
 	int bx = 0, by = 0, bz = 0;
 	if (live) {
 		bx = brick % nbx;
@@ -453,7 +460,7 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 	}
 	const int x0 = HW + bx * BX, y0 = HW + by * BY, z0 = HW + bz * BZ;
 	const int ex = min(BX, P.g.dims[0] - HW - x0), ey = min(BY, P.g.dims[1] - HW - y0), ez = min(BZ, P.g.dims[2] - HW - z0);
-	if (live && P.which != 0) {
+	if (live && P.which != 0 && !P.brick_list) {
 		const bool inner = x0 >= 2 * HW && y0 >= 2 * HW && z0 >= 2 * HW && x0 + ex <= P.g.dims[0] - 2 * HW &&
 						   y0 + ey <= P.g.dims[1] - 2 * HW && z0 + ez <= P.g.dims[2] - 2 * HW;
 		live = (P.which == 1) ? inner : !inner;
@@ -679,24 +686,82 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 	}
 }
 
+// Lists of the inner / boundary bricks of a grid for one brick shape ("inner": no halo cell inside the brick's shell),
+// built on the host when the grid or the shape changes (a few 10^4 entries).
+static bool brick_lists_for(BrickLists* bl, const Grid& g, int BX, int BY, int BZ, int nbx, int nby, int nbz) {
+	if (!bl) return false;
+	const int hw = g.hw;
+	if (bl->d[0] && bl->shape[0] == BX && bl->shape[1] == BY && bl->shape[2] == BZ && bl->hw == hw &&
+		bl->dims[0] == g.dims[0] && bl->dims[1] == g.dims[1] && bl->dims[2] == g.dims[2])
+		return true;
+	std::vector<uint32_t> lst[2];
+	for (int bz = 0; bz < nbz; ++bz)
+		for (int by = 0; by < nby; ++by)
+			for (int bx = 0; bx < nbx; ++bx) {
+				const int x0 = hw + bx * BX, y0 = hw + by * BY, z0 = hw + bz * BZ;
+				const int ex = std::min(BX, g.dims[0] - hw - x0), ey = std::min(BY, g.dims[1] - hw - y0),
+						  ez = std::min(BZ, g.dims[2] - hw - z0);
+				const bool inner = x0 >= 2 * hw && y0 >= 2 * hw && z0 >= 2 * hw && x0 + ex <= g.dims[0] - 2 * hw &&
+								   y0 + ey <= g.dims[1] - 2 * hw && z0 + ez <= g.dims[2] - 2 * hw;
+				lst[inner ? 0 : 1].push_back((uint32_t)((bz * nby + by) * nbx + bx));
+			}
+	for (int k = 0; k < 2; ++k) {
+		if (bl->d[k]) (void)hipFree(bl->d[k]);
+		bl->d[k] = nullptr;
+		bl->n[k] = (uint32_t)lst[k].size();
+		if (hipMalloc(&bl->d[k], std::max<size_t>(lst[k].size(), 1) * sizeof(uint32_t)) != hipSuccess) {
+			bl->d[k] = nullptr;
+			if (k == 1 && bl->d[0]) {
+				(void)hipFree(bl->d[0]);
+				bl->d[0] = nullptr;
+			}
+			return false;
+		}
+		if (!lst[k].empty() &&
+			hipMemcpy(bl->d[k], lst[k].data(), lst[k].size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+			return false;
+	}
+	bl->shape[0] = BX; bl->shape[1] = BY; bl->shape[2] = BZ;
+	bl->hw = hw;
+	for (int d = 0; d < 3; ++d) bl->dims[d] = g.dims[d];
+	return true;
+}
+
+// number of workgroups for a traversal; fills p.brick_list / p.n_list for the inner (1) / boundary (2) passes
+static long plan_bricks(ForceParams& p, BrickLists* bl, int BX, int BY, int BZ, int nbx, int nby, int nbz) {
+	long n = (long)nbx * nby * nbz;
+	p.brick_list = nullptr;
+	p.n_list = 0;
+	if ((p.which == 1 || p.which == 2) && brick_lists_for(bl, p.g, BX, BY, BZ, nbx, nby, nbz)) {
+		p.brick_list = bl->d[p.which - 1];
+		p.n_list = bl->n[p.which - 1];
+		n = p.n_list;
+	}
+	return 8 * ((n + 7) / 8);
+}
+
 template <int NT, int BY, int BZ, int CAPJ, int ROWS>
-static bool launch_mfma(const ForceParams& p, hipStream_t s, uint32_t* nblocks, size_t partials_cap) {
+static bool launch_mfma(ForceParams p, BrickLists* bl, hipStream_t s, uint32_t* nblocks, size_t partials_cap) {
 	const Grid& g = p.g;
 	const int nbx = g.box[0], nby = (g.box[1] + BY - 1) / BY, nbz = (g.box[2] + BZ - 1) / BZ;
-	const long nb = 8 * (((long)nbx * nby * nbz + 7) / 8);
-	if (nb <= 0 || (size_t)nb > partials_cap || nb > 0x7fffffffL) return false;
+	if ((long)nbx * nby * nbz <= 0 || (long)nbx * nby * nbz > 0x7ffffff0L) return false;
+	const long nb = plan_bricks(p, bl, 1, BY, BZ, nbx, nby, nbz);
+	if ((size_t)nb > partials_cap) return false;
 	*nblocks = (uint32_t)nb;
+	if (nb == 0) return true;
 	hipLaunchKernelGGL((k_force_lj_mfma<NT, BY, BZ, CAPJ, ROWS>), dim3((uint32_t)nb), dim3(NT), 0, s, p, nbx, nby, nbz);
 	return true;
 }
 
 template <int HW, int BX, int BY, int BZ, int CAPJ, int CAPL, int SPLIT>
-static bool launch_brick(const ForceParams& p, hipStream_t s, uint32_t* nblocks, size_t partials_cap) {
+static bool launch_brick(ForceParams p, BrickLists* bl, hipStream_t s, uint32_t* nblocks, size_t partials_cap) {
 	const Grid& g = p.g;
 	const int nbx = (g.box[0] + BX - 1) / BX, nby = (g.box[1] + BY - 1) / BY, nbz = (g.box[2] + BZ - 1) / BZ;
-	const long nb = 8 * (((long)nbx * nby * nbz + 7) / 8);
-	if (nb <= 0 || (size_t)nb > partials_cap || nb > 0x7fffffffL) return false;
+	if ((long)nbx * nby * nbz <= 0 || (long)nbx * nby * nbz > 0x7ffffff0L) return false;
+	const long nb = plan_bricks(p, bl, BX, BY, BZ, nbx, nby, nbz);
+	if ((size_t)nb > partials_cap) return false;
 	*nblocks = (uint32_t)nb;
+	if (nb == 0) return true;
 	hipLaunchKernelGGL((k_force_lj_brick<HW, BX, BY, BZ, CAPJ, CAPL, SPLIT>), dim3((uint32_t)nb), dim3(LTPB * SPLIT), 0, s,
 					   p, nbx, nby, nbz);
 	return true;
@@ -706,7 +771,7 @@ static bool launch_brick(const ForceParams& p, hipStream_t s, uint32_t* nblocks,
 // 4 = MFMA pre-filter kernel, 1x4x4-cell bricks, 512 threads; 5 = same with 256 threads (larger staging area);
 // 6 = MFMA kernel with 1x4x2-cell bricks (denser systems); 0 = choose from the mean cell occupancy.
 bool launch_force_lj(const ForceParams& p, hipStream_t s, uint32_t* nblocks, double* partials, size_t partials_cap,
-					 int split, double mean_per_cell) {
+					 int split, double mean_per_cell, BrickLists* bl) {
 	(void)partials;
 	if (split == 0) {
 		// staging capacity with 8 % headroom for density fluctuations; a brick that still overflows falls back (slowly)
@@ -718,15 +783,15 @@ bool launch_force_lj(const ForceParams& p, hipStream_t s, uint32_t* nblocks, dou
 		}
 	}
 	if (p.g.hw == 1) {
-		if (split == 4) return launch_mfma<512, 4, 4, 1680, 32>(p, s, nblocks, partials_cap);
-		if (split == 5) return launch_mfma<256, 4, 4, 2264, 32>(p, s, nblocks, partials_cap);
-		if (split == 6) return launch_mfma<512, 4, 2, 1680, 32>(p, s, nblocks, partials_cap);
-		if (split == 2) return launch_brick<1, 4, 2, 2, 1616, 38, 2>(p, s, nblocks, partials_cap);
-		return launch_brick<1, 4, 2, 2, 1656, 71, 1>(p, s, nblocks, partials_cap);
+		if (split == 4) return launch_mfma<512, 4, 4, 1680, 32>(p, bl, s, nblocks, partials_cap);
+		if (split == 5) return launch_mfma<256, 4, 4, 2264, 32>(p, bl, s, nblocks, partials_cap);
+		if (split == 6) return launch_mfma<512, 4, 2, 1680, 32>(p, bl, s, nblocks, partials_cap);
+		if (split == 2) return launch_brick<1, 4, 2, 2, 1616, 38, 2>(p, bl, s, nblocks, partials_cap);
+		return launch_brick<1, 4, 2, 2, 1656, 71, 1>(p, bl, s, nblocks, partials_cap);
 	}
 	if (p.g.hw == 2) {
-		if (split == 2 || split >= 4) return launch_brick<2, 8, 4, 4, 1440, 38, 2>(p, s, nblocks, partials_cap);
-		return launch_brick<2, 8, 4, 4, 1528, 63, 1>(p, s, nblocks, partials_cap);
+		if (split == 2 || split >= 4) return launch_brick<2, 8, 4, 4, 1440, 38, 2>(p, bl, s, nblocks, partials_cap);
+		return launch_brick<2, 8, 4, 4, 1528, 63, 1>(p, bl, s, nblocks, partials_cap);
 	}
 	return false;
 }

@@ -183,24 +183,36 @@ class DistributedSimulation:
         self.ex.exchange(HALO, overlap_fn=lambda: e.forces(1, want_macro=False))
         return e.forces(2)
 
-    def step(self, dt, want=False):
+    def _exchange_and_forces(self, want):
         e = self.engine
-        e.kick_drift(dt)
         e.rebin()
         self.ex.exchange(LEAVING)
         e.halo()
         # halo records travel while the compute stream traverses the inner cells
         self.ex.exchange(HALO, overlap_fn=lambda: e.forces(1, want_macro=False))
-        macro = e.forces(2, want_macro=want)
+        return e.forces(2, want_macro=want)
+
+    def step(self, dt, want=False):
+        e = self.engine
+        e.kick_drift(dt)
+        macro = self._exchange_and_forces(want)
         kin = e.kick(0.5 * dt, want_sums=want)
         return macro, kin
 
     def run(self, dt, nsteps):
+        """nsteps full time steps; between two steps the post-force kick and the next pre-force kick + drift are one
+        pass over the molecules (ls1hip_kick_then_kick_drift, bitwise the same as the two separate calls)."""
+        e = self.engine
         out = None
         for s in range(nsteps):
             last = s == nsteps - 1
-            macro, kin = self.step(dt, want=last)
+            if s == 0:
+                e.kick_drift(dt)
+            else:
+                e.kick_then_kick_drift(dt)
+            macro = self._exchange_and_forces(last)
             if last:
+                kin = e.kick(0.5 * dt, want_sums=True)
                 out = self.reduce_globals(macro, kin)
         return out
 

@@ -122,6 +122,10 @@ class DeviceEngine:
     def kick_drift(self, dt):
         self._chk(self.lib.ls1hip_kick_drift(self.ctx, float(dt)))
 
+    def kick_then_kick_drift(self, dt: float):
+        """Post-force kick of step n fused with the pre-force kick + drift of step n+1 (one pass)."""
+        self._chk(self.lib.ls1hip_kick_then_kick_drift(self.ctx, float(dt)))
+
     def rebin(self):
         self._chk(self.lib.ls1hip_rebin(self.ctx))
 

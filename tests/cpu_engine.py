@@ -46,6 +46,10 @@ class CpuEngine:
         self.v += 0.5 * dt / self.mass * self.F
         self.r += dt * self.v
 
+    def kick_then_kick_drift(self, dt):
+        self.v += 0.5 * dt / self.mass * self.F
+        self.kick_drift(dt)
+
     def rebin(self):
         s = np.where(self.r < self.bmin, -1, np.where(self.r >= self.bmax, 1, 0))
         out = [[] for _ in range(27)]

@@ -1,0 +1,22 @@
+import importlib, sys, time, os
+import numpy as np
+sys.path.insert(0, os.getcwd())
+import bench
+inp = importlib.import_module("ls1-mardyn_amd.inp")
+engine_mod = importlib.import_module("ls1-mardyn_amd.engine")
+import torch
+L, r, v = bench.bcc_box(171)
+eng = engine_mod.DeviceEngine(0)
+eng.set_components(bench.lj_components(inp), bench.RC)
+eng.set_domain([L, L, L])
+N = len(r)
+eng.upload(np.arange(1, N + 1, dtype=np.uint64), np.zeros(N, np.int32), r, v)
+eng.rebin(); eng.halo(); eng.forces(0)
+for which in ((0,), (1,), (2,), (1, 2)):
+    eng.timing_reset(); eng.timing_enable(True)
+    for _ in range(5):
+        for w in which:
+            eng.forces(w, want_macro=False)
+    torch.cuda.synchronize()
+    ms, n = eng.timing("force")
+    print(which, ms / 5, n)

@@ -130,22 +130,32 @@ class HaloExchanger:
             lst = [torch.empty_like(mine) for _ in range(self.dc.world)]
             dist.all_gather(lst, mine, group=self.group)
             allc = torch.stack(lst).cpu().numpy()
-        ops, recv_bufs, send_keep = [], [], []
-        for p in self.peers:
-            n_out = int(sum(counts[d] for d in self._outgoing[p]))
-            n_in = int(sum(allc[p][d] for d in self._incoming[p]))
-            if n_out:
-                buf = torch.empty(n_out * w, dtype=torch.float64, device=self.device)
-                self.engine.export_pack_dirs(kind, [d for d in self._outgoing[p] if counts[d]], self._ptr(buf), n_out)
-                if self.stage:
-                    torch.cuda.synchronize()
-                    buf = buf.cpu()
-                send_keep.append(buf)
-                ops.append(dist.P2POp(dist.isend, buf, p, group=self.group))
-            if n_in:
-                rb = torch.empty(n_in * w, dtype=torch.float64, device="cpu" if self.stage else self.device)
-                recv_bufs.append((rb, n_in))
-                ops.append(dist.P2POp(dist.irecv, rb, p, group=self.group))
+        # ONE device buffer holds every outgoing message (directions grouped by peer) and ONE every incoming message:
+        # one pack call / one import call / one stream synchronisation per exchange, whatever the number of peers
+        n_out = {p: int(sum(counts[d] for d in self._outgoing[p])) for p in self.peers}
+        n_in = {p: int(sum(allc[p][d] for d in self._incoming[p])) for p in self.peers}
+        tot_out, tot_in = sum(n_out.values()), sum(n_in.values())
+        ops = []
+        sbuf = rbuf = None
+        if tot_out:
+            sbuf = torch.empty(tot_out * w, dtype=torch.float64, device=self.device)
+            order = [d for p in self.peers for d in self._outgoing[p] if counts[d]]
+            self.engine.export_pack_dirs(kind, order, self._ptr(sbuf), tot_out)
+            if self.stage:
+                torch.cuda.synchronize()
+                sbuf = sbuf.cpu()
+            off = 0
+            for p in self.peers:
+                if n_out[p]:
+                    ops.append(dist.P2POp(dist.isend, sbuf[off * w:(off + n_out[p]) * w], p, group=self.group))
+                    off += n_out[p]
+        if tot_in:
+            rbuf = torch.empty(tot_in * w, dtype=torch.float64, device="cpu" if self.stage else self.device)
+            off = 0
+            for p in self.peers:
+                if n_in[p]:
+                    ops.append(dist.P2POp(dist.irecv, rbuf[off * w:(off + n_in[p]) * w], p, group=self.group))
+                    off += n_in[p]
         reqs = dist.batch_isend_irecv(ops) if ops else []
         if overlap_fn is not None:
             overlap_fn()
@@ -153,14 +163,12 @@ class HaloExchanger:
             r.wait()
         if self.device.type == "cuda":
             torch.cuda.current_stream().synchronize()
-        keep = []  # imports are asynchronous: the device buffers live until import_done has returned
-        for rb, n_in in recv_bufs:
+        if tot_in:
             if self.stage:
-                rb = rb.to(self.device)
-            keep.append(rb)
-            self.engine.import_records(kind, self._ptr(rb), n_in)
+                rbuf = rbuf.to(self.device)
+            self.engine.import_records(kind, self._ptr(rbuf), tot_in)  # asynchronous: rbuf lives until import_done
         self.engine.import_done(kind)
-        del keep
+        del sbuf, rbuf
 
 
 class DistributedSimulation:

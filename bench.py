@@ -30,6 +30,10 @@ RC = 2.5
 DT = 0.002
 TEMP = 0.95
 FORCE_BYTES_PER_MOLECULE = 48.0   # read r (24 B) + write F (24 B): SURVEY.md 8(d)
+# fused force + integration pass (between steps, reduced-memory mode): read r, v (48 B) + write r', v' (48 B); F never
+# reaches HBM and the 120 B integrator pass disappears (SURVEY.md 8(d) force 48 B + integrator 120 B -> 96 B)
+FUSED_BYTES_PER_MOLECULE = 96.0
+PMC_SUMMARY = "r1_e_pmc_summary.json"  # rocprofv3 PMC passes of this workload (tools/collect_profiles.sh)
 STEP_BYTES_PER_MOLECULE = 292.0   # full step: force 48 + integrator 120 + re-bin 124
 HBM_PEAK_GBS = 8000.0
 
@@ -136,6 +140,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="force kernel variant (LS1HIP_FK_*)")
     ap.add_argument("--cic", type=int, default=0, help="cells in cutoff (0 = engine default)")
     ap.add_argument("--split", type=int, default=0, help="lanes per molecule in the LDS LJ kernel (0 = engine default)")
+    ap.add_argument("--no-fuse", action="store_true", help="separate integrator passes instead of the fused force pass")
     ap.add_argument("--decomp", action="store_true",
                     help="diagnostic: run the decomposed (multi-rank) step loop even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -192,9 +197,12 @@ def main():
         sim = None
         n_total = N
 
+    if args.no_fuse:
+        (sim.engine if sim is not None else eng).set_option("fuse_integration", 0)
+
     def run(k):
         if sim is not None:
-            return sim.run(DT, k)
+            return sim.run(DT, k, fuse=not args.no_fuse)
         return eng.run(DT, k)
 
     def sync():
@@ -227,19 +235,24 @@ def main():
     n_local = e.count()[0]
     # HBM traffic of the force kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction, WRITE_SIZE), taken
     # offline on this exact workload and committed under profiles/ (PMC collection cannot run inside the timed loop)
+    fused_on = bool(e.get_option("fuse_integration")) and bool(e.get_option("can_fuse_integration"))
+    n_fused = (args.steps - 1) if fused_on else 0  # the last step of a run is unfused (F and kinetic sums are needed)
+    alg_bytes_total = n_local * (FUSED_BYTES_PER_MOLECULE * n_fused + FORCE_BYTES_PER_MOLECULE * (args.steps - n_fused))
+    alg_bytes_per_launch = alg_bytes_total / max(force_n, 1)
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_d_pmc_summary.json")) as fh:
-            pm = json.load(fh)["force_kernel"]
-        if world == 1 and abs(pm["algorithmic_bytes_per_launch"] - FORCE_BYTES_PER_MOLECULE * n_local) < 1 and \
-                e.get_option("cells_in_cutoff") == 1 and e.get_option("force_kernel") in (0, 2) and \
-                e.get_option("lj_split") == 0:
+        with open(os.path.join(ROOT, "profiles", PMC_SUMMARY)) as fh:
+            js = json.load(fh)
+        pm = js["force_kernel"]
+        if world == 1 and js.get("molecules") == n_local and e.get_option("cells_in_cutoff") == 1 and \
+                e.get_option("force_kernel") in (0, 2) and e.get_option("lj_split") == 0 and \
+                abs(pm["algorithmic_bytes_per_launch"] / alg_bytes_per_launch - 1.0) < 0.03:
             traffic = pm["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
     if rank == 0:
         avg_force_s = force_ms / 1e3 / max(force_n, 1)
-        achieved = FORCE_BYTES_PER_MOLECULE * n_local / avg_force_s / 1e9
+        achieved = alg_bytes_total / (force_ms / 1e3) / 1e9
         value = n_total * args.steps / elapsed
         out = {
             "metric": "particle-updates/sec (whole node), 1CLJ liquid Argon-like LJ, rc=2.5 sigma",
@@ -249,11 +262,13 @@ def main():
             "config": {"workload": f"1CLJ Lennard-Jones liquid, N={n_total} (2*{n}^3 per GPU), rho*={RHO}, rc={RC} sigma, "
                                    f"dt={DT}, T*={TEMP}, NVE full time step (kick-drift, re-bin, halo, forces, kick), FP64",
                        "molecules_per_gpu": n_local, "decomposition": getattr(sim, "grid_desc", "single GPU, periodic images local"),
-                       "force_kernel": e.get_option("force_kernel"), "cells_in_cutoff": e.get_option("cells_in_cutoff")},
+                       "force_kernel": e.get_option("force_kernel"), "cells_in_cutoff": e.get_option("cells_in_cutoff"),
+                       "integration": ("fused into the force pass between steps (reduced-memory mode), last step separate"
+                                       if fused_on else "separate integrator passes")},
             "roofline": {"bound": "hbm", "kernel": "pair-force traversal (k_force_*)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_force_s * 1e3, "launches": int(force_n),
-                         "algorithmic_bytes_per_launch": FORCE_BYTES_PER_MOLECULE * n_local,
+                         "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "full_step_frac": STEP_BYTES_PER_MOLECULE * n_total / world * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
             "device_ms_per_step": {"force": force_ms / args.steps, "integrate": integ_ms / args.steps,
                                    "rebin": rebin_ms / args.steps, "halo": halo_ms / args.steps},

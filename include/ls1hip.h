@@ -68,6 +68,8 @@ const char* ls1hip_version(void);
  * "deterministic" (0|1 canonical in-cell order by molecule id),
  * "count_pairs" (0|1 tally molecule pairs / site interactions inside the cutoff for ls1hip_pair_stats — the
  * counters of adapter/FlopCounter.cpp:20-76; forces then use the generic kernel),
+ * "fuse_integration" (0|1, default 1: ls1hip_run lets the force pass do the integration between steps, see
+ * ls1hip_forces_kick_drift), "can_fuse_integration" (read only),
  * "lj_split" (variant of the single-centre LJ fast path; results are the same to rounding, only speed differs:
  *   0 = choose from the mean cell occupancy (default); 1 | 2 = list kernel with 1 | 2 lanes per molecule;
  *   4 = FP32 MFMA distance-tile pre-filter + exact FP64 evaluation, 1x4x4-cell bricks, 512 threads;
@@ -154,6 +156,17 @@ int ls1hip_forces(ls1hip_ctx* ctx, int which, double* upot, double* virial);
 /* Leapfrog::eventForcesCalculated -> FullMolecule::upd_postF (Leapfrog.cpp:66-150, FullMolecule.cpp:366-389):
  * v += dt_half/m F; L += dt_half M; returns sum m v^2, sum I w^2, N, rotational DOF (thermostat 0). */
 int ls1hip_kick(ls1hip_ctx* ctx, double dt_half, double* summv2, double* sumIw2, uint64_t* n, uint64_t* rot_dof);
+
+/* Force pass that consumes the forces at once (reduced-memory mode; the reference's counterpart is the RMM pair
+ * VCP1CLJRMM::processCell* + LeapfrogRMM, particleContainer/adapter/VCP1CLJRMM.cpp:241-369, integrators/LeapfrogRMM.cpp):
+ * ls1hip_forces(which) fused with the post-force kick of this step and the pre-force kick + drift of the NEXT step,
+ * arithmetic identical to ls1hip_forces + ls1hip_kick_then_kick_drift(dt) (bitwise).  F is never stored (-48 B of
+ * HBM traffic per molecule, no separate integrator pass); the advanced positions are picked up by the following
+ * ls1hip_rebin.  Afterwards velocities are at the half step, forces are NOT available (ls1hip_download_forces fails
+ * until the next ls1hip_forces).  which = 0, or 1 followed by 2 (overlap split), as for ls1hip_forces; U_pot / virial
+ * as there.  Available when ls1hip_get_option("can_fuse_integration") is 1: single-centre LJ fast path, no per-molecule
+ * virial, no device thermostat.  ls1hip_run uses it between steps unless option "fuse_integration" is 0. */
+int ls1hip_forces_kick_drift(ls1hip_ctx* ctx, int which, double dt, double* upot, double* virial);
 
 /* eventForcesCalculated of step n immediately followed by eventNewTimestep of step n+1 (Leapfrog.cpp:66-150 then
  * :48-64) in ONE pass over the molecules: v += dt/m F; r += dt v (and the rotational counterparts) — bitwise the same

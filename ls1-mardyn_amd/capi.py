@@ -41,6 +41,7 @@ SYMBOLS = {
     "ls1hip_rebin": (C.c_int, [C.c_void_p]),
     "ls1hip_halo": (C.c_int, [C.c_void_p]),
     "ls1hip_forces": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp]),
+    "ls1hip_forces_kick_drift": (C.c_int, [C.c_void_p, C.c_int, C.c_double, _dp, _dp]),
     "ls1hip_kick": (C.c_int, [C.c_void_p, C.c_double, _dp, _dp, _u64p, _u64p]),
     "ls1hip_scale_velocities": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "ls1hip_set_thermostat": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),

@@ -164,6 +164,12 @@ extern "C" int ls1hip_destroy(ls1hip_ctx* c) {
 	return LS1HIP_OK;
 }
 
+// the fused force -> kick -> drift pass exists for the single-centre LJ brick kernels only
+static bool can_fuse(const ls1hip_ctx* c) {
+	return c->one_clj && c->opt_force_kernel != LS1HIP_FK_GENERIC && !c->opt_vi && !c->opt_count_pairs && !c->thermostat_on &&
+		   (c->g.hw == 1 || c->g.hw == 2);
+}
+
 extern "C" int ls1hip_set_option(ls1hip_ctx* c, const char* name, long v) {
 	if (!c || !name) return LS1HIP_EINVAL;
 	std::string n(name);
@@ -180,6 +186,8 @@ extern "C" int ls1hip_set_option(ls1hip_ctx* c, const char* name, long v) {
 		c->opt_det = v ? 1 : 0;
 	} else if (n == "count_pairs") {
 		c->opt_count_pairs = v ? 1 : 0;
+	} else if (n == "fuse_integration") {
+		c->opt_fuse = v ? 1 : 0;
 	} else if (n == "lj_split") {
 		REQUIRE(c, v == 0 || v == 1 || v == 2 || v == 4 || v == 5 || v == 6, "lj_split must be 0 (auto), 1, 2 (list kernel lanes per molecule), 4, 5 or 6 (MFMA pre-filter variants)");
 		c->opt_lj_split = v;
@@ -198,6 +206,8 @@ extern "C" int ls1hip_get_option(const ls1hip_ctx* c, const char* name, long* v)
 	else if (n == "deterministic") *v = c->opt_det;
 	else if (n == "count_pairs") *v = c->opt_count_pairs;
 	else if (n == "lj_split") *v = c->opt_lj_split;
+	else if (n == "fuse_integration") *v = c->opt_fuse;
+	else if (n == "can_fuse_integration") *v = can_fuse(c) ? 1 : 0;
 	else return LS1HIP_EINVAL;
 	return LS1HIP_OK;
 }
@@ -559,6 +569,8 @@ extern "C" int ls1hip_upload(ls1hip_ctx* c, size_t n, const uint64_t* id, const 
 	c->binned = false;
 	c->halo_valid = false;
 	c->forces_valid = false;
+	c->pos_in_F = false;
+	c->fused_split = 0;
 	return LS1HIP_OK;
 }
 
@@ -585,6 +597,11 @@ static RebinArgs rebin_args(ls1hip_ctx* c, uint32_t n_in) {
 	RebinArgs a;
 	a.g = c->g;
 	a.src = c->mol[c->cur];
+	if (c->pos_in_F) {  // a fused force pass left the advanced positions of the owned molecules in the force arrays
+		a.src.x = c->frc.Fx;
+		a.src.y = c->frc.Fy;
+		a.src.z = c->frc.Fz;
+	}
 	a.dst = c->mol[c->cur ^ 1];
 	a.has_rot = c->h_ct.has_rot;
 	a.key = c->d_key; a.rank = c->d_rank; a.perm = c->d_perm; a.ckey = c->d_ckey; a.idk = c->d_idk;
@@ -629,6 +646,7 @@ static int do_rebin_finish(ls1hip_ctx* c, uint32_t n_in) {
 	launch_rebin_sort_gather(a, c->stream);
 	HIPCHK(c, hipGetLastError());
 	c->cur ^= 1;
+	c->pos_in_F = false;
 	c->binned = true;
 	c->halo_valid = false;
 	c->forces_valid = false;
@@ -665,7 +683,7 @@ extern "C" int ls1hip_halo(ls1hip_ctx* c) {
 	return LS1HIP_OK;
 }
 
-static int launch_forces(ls1hip_ctx* c, int which) {
+static int launch_forces(ls1hip_ctx* c, int which, bool fuse = false, double dt = 0.) {
 	ForceParams P;
 	memset(&P, 0, sizeof(P));
 	const MolSoA& m = c->mol[c->cur];
@@ -685,6 +703,12 @@ static int launch_forces(ls1hip_ctx* c, int which) {
 	P.sig2 = c->h_ct.sig2[0];
 	P.shift6 = c->h_ct.shift6[0];
 	P.rc2 = c->h_ct.rc2;
+	if (fuse) {
+		P.fuse = 1;
+		P.dt = dt;
+		P.dt_inv2m = (.5 * dt) / c->h_ct.mass[0];  // as k_kick_then_kick_drift: dt_halve / mass
+		P.vx = m.vx; P.vy = m.vy; P.vz = m.vz;
+	}
 	uint32_t nblocks = 0;
 	if (which == 0 || which == 1) launch_clear_macro(c->d_cnt, c->stream);
 	bool done = false;
@@ -693,6 +717,7 @@ static int launch_forces(ls1hip_ctx* c, int which) {
 		done = launch_force_lj(P, c->stream, &nblocks, c->d_partials, c->partials_cap, (int)c->opt_lj_split,
 							   ncell > 0 ? (double)c->n_real / ncell : 0., &c->brick_lists);
 	}
+	if (!done && fuse) FAIL(c, LS1HIP_EINVAL, "fused force + integration needs the single-centre LJ fast path");
 	if (!done) {
 		if (c->opt_force_kernel == LS1HIP_FK_LDS_LIST && !c->one_clj)
 			FAIL(c, LS1HIP_EINVAL, "force_kernel=LDS_LIST supports single-centre LJ components only");
@@ -714,6 +739,7 @@ extern "C" int ls1hip_forces(ls1hip_ctx* c, int which, double* upot, double* vir
 	REQUIRE(c, which >= 0 && which <= 2, "which must be 0, 1 or 2");
 	REQUIRE(c, c->binned, "molecules are not binned (call ls1hip_rebin)");
 	REQUIRE(c, which == 1 || c->halo_valid, "halo not populated (call ls1hip_halo / import_done(1))");
+	REQUIRE(c, !c->fused_split, "a fused inner pass (ls1hip_forces_kick_drift which=1) must be completed by its which=2 pass");
 	HIPCHK(c, hipSetDevice(c->device));
 	{
 		TimedScope ts(c, c->t_force);
@@ -726,6 +752,50 @@ extern "C" int ls1hip_forces(ls1hip_ctx* c, int which, double* upot, double* vir
 		if (rc) return rc;
 		macro_to_upot_virial(c->h_cnt, upot, virial);
 	}
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_forces_kick_drift(ls1hip_ctx* c, int which, double dt, double* upot, double* virial) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, which >= 0 && which <= 2, "which must be 0, 1 or 2");
+	REQUIRE(c, c->binned, "molecules are not binned (call ls1hip_rebin)");
+	REQUIRE(c, which == 1 || c->halo_valid, "halo not populated (call ls1hip_halo / import_done(1))");
+	REQUIRE(c, can_fuse(c), "fused force + integration: single-centre LJ fast path, no per-molecule virial, no device thermostat");
+	REQUIRE(c, which == 2 ? c->fused_split == 1 : c->fused_split == 0, "fused passes must be which=0, or which=1 followed by which=2");
+	HIPCHK(c, hipSetDevice(c->device));
+	{
+		TimedScope ts(c, c->t_force);
+		int rc = launch_forces(c, which, true, dt);
+		if (rc) return rc;
+	}
+	if (which == 1) {
+		c->fused_split = 1;
+	} else {
+		// velocities are at t + dt/2 of the NEXT step and the advanced positions wait in the force arrays for ls1hip_rebin
+		c->fused_split = 0;
+		c->pos_in_F = true;
+		c->binned = false;
+		c->halo_valid = false;
+		c->forces_valid = false;
+	}
+	if (upot || virial) {
+		int rc = sync_counters(c);
+		if (rc) return rc;
+		macro_to_upot_virial(c->h_cnt, upot, virial);
+	}
+	return LS1HIP_OK;
+}
+
+// positions parked in the force arrays by a fused pass -> back into the molecule arrays (readers other than ls1hip_rebin)
+static int materialise_positions(ls1hip_ctx* c) {
+	if (!c->pos_in_F) return LS1HIP_OK;
+	const MolSoA& m = c->mol[c->cur];
+	const uint32_t n = (uint32_t)c->n_real;
+	launch_pack_copy(m.x, c->frc.Fx, n, c->stream);
+	launch_pack_copy(m.y, c->frc.Fy, n, c->stream);
+	launch_pack_copy(m.z, c->frc.Fz, n, c->stream);
+	HIPCHK(c, hipGetLastError());
+	c->pos_in_F = false;
 	return LS1HIP_OK;
 }
 
@@ -745,6 +815,7 @@ static IntegArgs integ_args(ls1hip_ctx* c, double dt) {
 extern "C" int ls1hip_kick_drift(ls1hip_ctx* c, double dt) {
 	if (!c) return LS1HIP_EINVAL;
 	REQUIRE(c, c->cap_real, "no molecules uploaded");
+	REQUIRE(c, !c->pos_in_F && !c->fused_split, "positions were already advanced by ls1hip_forces_kick_drift (call ls1hip_rebin)");
 	HIPCHK(c, hipSetDevice(c->device));
 	TimedScope ts(c, c->t_integrate);
 	launch_kick_drift(integ_args(c, dt), c->stream);
@@ -895,9 +966,15 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 	REQUIRE(c, !c->has_remote, "ls1hip_run drives single-rank domains only (use the piecewise calls with a transport)");
 	REQUIRE(c, c->forces_valid, "initial forces required (rebin, halo, forces) before ls1hip_run");
 	HIPCHK(c, hipSetDevice(c->device));
+	// Between two steps of an NVE run on the LJ fast path the force pass does the integration itself (fused mode, the
+	// reference's reduced-memory scheme); the last step is unfused so that F and the kinetic sums are available.
+	const bool fuse = c->opt_fuse && can_fuse(c);
+	bool advanced = false;  // the previous force pass already did kick + kick + drift
 	for (unsigned long s = 0; s < nsteps; ++s) {
 		int rc;
-		if (s == 0) {
+		if (advanced) {
+			// nothing to integrate: positions wait in the force arrays for the re-binning pass
+		} else if (s == 0) {
 			if ((rc = ls1hip_kick_drift(c, dt))) return rc;
 		} else if (c->thermostat_on) {
 			// NVT: the scaling factors depend on the kinetic sums after the kick, so the two half kicks stay separate
@@ -912,7 +989,11 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 			// post-force kick of step s-1 fused with the pre-force kick+drift of step s (same F, one pass)
 			if ((rc = ls1hip_kick_then_kick_drift(c, dt))) return rc;
 		}
-		if ((rc = ls1hip_rebin(c)) || (rc = ls1hip_halo(c)) || (rc = ls1hip_forces(c, 0, nullptr, nullptr))) return rc;
+		if ((rc = ls1hip_rebin(c)) || (rc = ls1hip_halo(c))) return rc;
+		advanced = fuse && s + 1 < nsteps;
+		if (advanced) rc = ls1hip_forces_kick_drift(c, 0, dt, nullptr, nullptr);
+		else rc = ls1hip_forces(c, 0, nullptr, nullptr);
+		if (rc) return rc;
 		if (s + 1 == nsteps) {
 			if ((rc = ls1hip_kick(c, 0.5 * dt, nullptr, nullptr, nullptr, nullptr))) return rc;
 			if (c->thermostat_on) {
@@ -952,12 +1033,14 @@ extern "C" int ls1hip_download_state(ls1hip_ctx* c, size_t cap, uint64_t* id, in
 									 double* q, double* D) {
 	if (!c) return LS1HIP_EINVAL;
 	HIPCHK(c, hipSetDevice(c->device));
+	REQUIRE(c, !c->fused_split, "state is half advanced (complete the fused which=2 pass first)");
+	int rc;
+	if ((rc = materialise_positions(c))) return rc;
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	const size_t n = c->n_real;
 	REQUIRE(c, cap >= n, "buffer too small: %zu < %zu", cap, n);
 	if (n == 0) return LS1HIP_OK;
 	const MolSoA& m = c->mol[c->cur];
-	int rc;
 	if (id) HIPCHK(c, hipMemcpy(id, m.id, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
 	if (cid) HIPCHK(c, hipMemcpy(cid, m.cid, n * sizeof(int32_t), hipMemcpyDeviceToHost));
 	if (r && (rc = d2h3(c, n, m.x, m.y, m.z, r, 3, 0))) return rc;

@@ -69,6 +69,10 @@ struct ForceParams {
 	int count_pairs;
 	const uint32_t* brick_list;  // LJ brick kernels: bricks of this pass (inner / boundary), nullptr = all bricks
 	uint32_t n_list;
+	// fused force -> kick -> kick -> drift (LJ fast path only): v updated in place, new positions written to Fx/Fy/Fz
+	int fuse;
+	double dt, dt_inv2m;
+	double *vx, *vy, *vz;
 	// 1CLJ fast-path scalars
 	double eps24, sig2, shift6, rc2;
 };
@@ -96,6 +100,9 @@ struct ls1hip_ctx {
 	// options
 	long opt_force_kernel = LS1HIP_FK_AUTO, opt_cic = 1, opt_vi = 0, opt_det = 1, opt_count_pairs = 0, opt_lj_split = 0;
 	ls1::BrickLists brick_lists;
+	long opt_fuse = 1;       // ls1hip_run: fuse force + integration between steps when possible
+	bool pos_in_F = false;   // positions of the owned molecules live in frc.F* (after a fused force pass)
+	int fused_split = 0;     // a fused which=1 pass is waiting for its which=2 pass
 	// model
 	bool have_comp = false, have_domain = false;
 	ls1::CompTable h_ct;

@@ -82,6 +82,34 @@ __device__ __forceinline__ void lj_pair_in(double xi, double yi, double zi, doub
 	a.vir = fma(fac, r2, a.vir);
 }
 
+// Epilogue of an owned molecule.  Normal mode: store F.  Fused mode (ForceParams::fuse, the reference's reduced-memory
+// scheme VCP1CLJRMM.cpp:241-369 + LeapfrogRMM): the force is consumed at once by the post-force kick of this step and
+// the pre-force kick + drift of the next (the arithmetic of k_kick_then_kick_drift, operation for operation): v is
+// updated in place and the NEW position goes to the F arrays (the old positions are still being read by other bricks),
+// from where the next re-binning pass picks it up.  F is never written: -48 B of HBM traffic per molecule and no
+// separate integrator pass.
+__device__ __forceinline__ void lj_store(const ForceParams& P, uint32_t gi, const LjAcc& acc) {
+	if (!P.fuse) {
+		P.Fx[gi] = acc.fx;
+		P.Fy[gi] = acc.fy;
+		P.Fz[gi] = acc.fz;
+		return;
+	}
+	const double k = P.dt_inv2m;
+	double vx = P.vx[gi] + k * acc.fx;  // upd_postF
+	double vy = P.vy[gi] + k * acc.fy;
+	double vz = P.vz[gi] + k * acc.fz;
+	vx += k * acc.fx;  // upd_preF
+	vy += k * acc.fy;
+	vz += k * acc.fz;
+	P.vx[gi] = vx;
+	P.vy[gi] = vy;
+	P.vz[gi] = vz;
+	P.Fx[gi] = P.x[gi] + P.dt * vx;
+	P.Fy[gi] = P.y[gi] + P.dt * vy;
+	P.Fz[gi] = P.z[gi] + P.dt * vz;
+}
+
 __device__ __forceinline__ double wave_sum_lj(double v) {
 	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
 	return v;
@@ -343,11 +371,7 @@ __global__ void __launch_bounds__(LTPB * SPLIT, 2 * SPLIT) k_force_lj_brick(Forc
 			acc.fy += __shfl_xor(acc.fy, 1);
 			acc.fz += __shfl_xor(acc.fz, 1);
 		}
-		if (active && half == 0) {
-			P.Fx[gi] = acc.fx;
-			P.Fy[gi] = acc.fy;
-			P.Fz[gi] = acc.fz;
-		}
+		if (active && half == 0) lj_store(P, gi, acc);
 		u6_tot += acc.u6;
 		vir_tot += acc.vir;
 	}
@@ -657,11 +681,7 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 			acc.fx += __shfl_xor(acc.fx, 32);
 			acc.fy += __shfl_xor(acc.fy, 32);
 			acc.fz += __shfl_xor(acc.fz, 32);
-			if (valid && grp == 0) {
-				P.Fx[gi] = acc.fx;
-				P.Fy[gi] = acc.fy;
-				P.Fz[gi] = acc.fz;
-			}
+			if (valid && grp == 0) lj_store(P, gi, acc);
 			u6_tot += acc.u6;
 			vir_tot += acc.vir;
 		}

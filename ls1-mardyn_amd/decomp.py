@@ -191,14 +191,19 @@ class DistributedSimulation:
         self.ex.exchange(HALO, overlap_fn=lambda: e.forces(1, want_macro=False))
         return e.forces(2)
 
-    def _exchange_and_forces(self, want):
+    def _exchange_and_forces(self, want, fuse_dt=None):
+        """re-bin + migration, halo exchange overlapped with the inner-cell traversal, boundary traversal.  With
+        fuse_dt the force passes also integrate (ls1hip_forces_kick_drift): no F round trip, no integrator pass."""
         e = self.engine
         e.rebin()
         self.ex.exchange(LEAVING)
         e.halo()
         # halo records travel while the compute stream traverses the inner cells
-        self.ex.exchange(HALO, overlap_fn=lambda: e.forces(1, want_macro=False))
-        return e.forces(2, want_macro=want)
+        if fuse_dt is None:
+            self.ex.exchange(HALO, overlap_fn=lambda: e.forces(1, want_macro=False))
+            return e.forces(2, want_macro=want)
+        self.ex.exchange(HALO, overlap_fn=lambda: e.forces_kick_drift(1, fuse_dt))
+        return e.forces_kick_drift(2, fuse_dt, want_macro=want)
 
     def step(self, dt, want=False):
         e = self.engine
@@ -207,18 +212,25 @@ class DistributedSimulation:
         kin = e.kick(0.5 * dt, want_sums=want)
         return macro, kin
 
-    def run(self, dt, nsteps):
-        """nsteps full time steps; between two steps the post-force kick and the next pre-force kick + drift are one
-        pass over the molecules (ls1hip_kick_then_kick_drift, bitwise the same as the two separate calls)."""
+    def run(self, dt, nsteps, fuse=True):
+        """nsteps full time steps.  Between two steps the post-force kick and the next pre-force kick + drift are
+        either done by the force pass itself (fused / reduced-memory mode, when the engine offers it) or by one pass
+        over the molecules (ls1hip_kick_then_kick_drift); both are bitwise the same as the separate calls.  The last
+        step is unfused: forces and kinetic sums are needed for the global values."""
         e = self.engine
+        fuse = bool(fuse) and getattr(e, "can_fuse_integration", lambda: False)()
         out = None
+        advanced = False
         for s in range(nsteps):
             last = s == nsteps - 1
-            if s == 0:
+            if advanced:
+                pass  # positions already advanced by the previous force pass
+            elif s == 0:
                 e.kick_drift(dt)
             else:
                 e.kick_then_kick_drift(dt)
-            macro = self._exchange_and_forces(last)
+            advanced = fuse and not last
+            macro = self._exchange_and_forces(last, dt if advanced else None)
             if last:
                 kin = e.kick(0.5 * dt, want_sums=True)
                 out = self.reduce_globals(macro, kin)

@@ -122,6 +122,18 @@ class DeviceEngine:
     def kick_drift(self, dt):
         self._chk(self.lib.ls1hip_kick_drift(self.ctx, float(dt)))
 
+    def forces_kick_drift(self, which: int, dt: float, want_macro: bool = False):
+        """Force pass fused with kick + kick + drift (reduced-memory mode); see ls1hip_forces_kick_drift."""
+        if not want_macro:
+            self._chk(self.lib.ls1hip_forces_kick_drift(self.ctx, int(which), float(dt), None, None))
+            return None
+        u = C.c_double(); w = C.c_double()
+        self._chk(self.lib.ls1hip_forces_kick_drift(self.ctx, int(which), float(dt), C.byref(u), C.byref(w)))
+        return u.value, w.value
+
+    def can_fuse_integration(self) -> bool:
+        return bool(self.get_option("can_fuse_integration"))
+
     def kick_then_kick_drift(self, dt: float):
         """Post-force kick of step n fused with the pre-force kick + drift of step n+1 (one pass)."""
         self._chk(self.lib.ls1hip_kick_then_kick_drift(self.ctx, float(dt)))

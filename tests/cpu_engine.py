@@ -157,6 +157,17 @@ class CpuEngine:
         self.macro = np.array([u6 / 6.0, vir])
         return (self.macro[0], self.macro[1]) if want_macro else None
 
+    def can_fuse_integration(self):
+        return True
+
+    def forces_kick_drift(self, which, dt, want_macro=False):
+        """forces(which) fused with kick + kick + drift of the next step (which=1 is a no-op in this stand-in)"""
+        out = self.forces(which, want_macro)
+        if which != 1:
+            self.v += 0.5 * dt / self.mass * self.F
+            self.kick_drift(dt)
+        return out
+
     def kick(self, dt_half, want_sums=True):
         self.v += dt_half / self.mass * self.F
         return (float(self.mass * (self.v ** 2).sum()), 0.0, len(self.v), 0) if want_sums else None

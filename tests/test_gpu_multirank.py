@@ -76,6 +76,19 @@ class InProcessCluster:
             tot += np.array(e.forces(2 if split else 0))
         return tot
 
+    def fused_forces(self, dt):
+        """re-bin, exchange, inner pass, halo exchange, boundary pass with the integration fused into the force passes"""
+        for e in self.eng:
+            e.rebin()
+        self.exchange(decomp.LEAVING)
+        for e in self.eng:
+            e.halo()
+        for e in self.eng:
+            e.forces_kick_drift(1, dt)
+        self.exchange(decomp.HALO)
+        for e in self.eng:
+            e.forces_kick_drift(2, dt)
+
     def step(self, dt):
         for e in self.eng:
             e.kick_drift(dt)
@@ -135,3 +148,35 @@ def test_subboxes_equal_single_domain(world, grid):
     assert np.allclose(k1, km, rtol=1e-12)
     moved = sum(e.count()[0] for e in multi.eng)
     assert moved == len(ids)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_fused_integration_across_subboxes(world):
+    """Reduced-memory mode on a decomposed domain: sub-boxes running fused inner/boundary passes with migration and halo
+    exchange in between == the single domain running the ordinary loop."""
+    L, r, v = _liquid(16)
+    rc, dt, nsteps = 2.5, 0.004, 5
+    ids = np.arange(1, len(r) + 1, dtype=np.uint64)
+    comps = inp.ComponentSet([inp.make_component(lj=[(0, 0, 0, 1, 1, 1, rc, 0)])], np.zeros((0, 2)), 1e10)
+    single = InProcessCluster(1, comps, rc, L, ids, r, v)
+    multi = InProcessCluster(world, comps, rc, L, ids, r, v)
+    single.forces(split=False)
+    multi.forces()
+    for _ in range(nsteps):
+        single.step(dt)
+    for e in multi.eng:
+        e.kick_drift(dt)
+    for s in range(nsteps):
+        if s + 1 < nsteps:
+            multi.fused_forces(dt)
+        else:
+            multi.forces()
+            for e in multi.eng:
+                e.kick(0.5 * dt)
+    a, b = single.gather(), multi.gather()
+    assert np.array_equal(a["ids"], b["ids"])
+    dr = a["r"] - b["r"]
+    dr -= L * np.round(dr / L)
+    assert np.max(np.abs(dr)) < 1e-11
+    assert np.max(np.abs(a["v"] - b["v"])) < 1e-11 * np.max(np.abs(a["v"]))
+    assert np.max(np.abs(a["F"] - b["F"])) < 1e-10 * np.max(np.abs(a["F"]))

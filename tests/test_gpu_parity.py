@@ -200,6 +200,66 @@ def test_device_loop_equals_piecewise_calls():
     assert res[0][2] == res[1][2]
 
 
+@pytest.mark.parametrize("cic,split", [(1, 0), (1, 2), (1, 6), (2, 0)])
+def test_fused_force_integration_is_bitwise_the_unfused_loop(cic, split):
+    """SURVEY 8f-4 (reduced-memory mode): ls1hip_run with the force pass doing kick + kick + drift between steps
+    (ls1hip_forces_kick_drift) == the same run with separate integrator passes, bit for bit: positions, velocities,
+    forces of the last step, U_pot, virial, kinetic sum.  Also the piecewise fused calls incl. the inner/boundary
+    split and the state rules (no F after a fused pass, download_state sees the advanced positions)."""
+    L, r, v = _bcc(24, seed=3)
+    N = len(r)
+    comp = inp.ComponentSet([inp.make_component(lj=[(0, 0, 0, 1, 1, 1, 2.5, 0)])], np.zeros((0, 2)), 1e10)
+    engine_mod = load_pkg("engine")
+    dt, nsteps = 0.002, 7
+    out = {}
+    for mode in ("unfused", "fused", "piecewise"):
+        e = engine_mod.DeviceEngine(0)
+        e.set_components(comp, 2.5)
+        e.set_option("cells_in_cutoff", cic)
+        e.set_option("lj_split", split)
+        e.set_option("fuse_integration", 0 if mode == "unfused" else 1)
+        e.set_domain([L, L, L])
+        assert e.get_option("can_fuse_integration") == 1
+        e.upload(np.arange(1, N + 1, dtype=np.uint64), np.zeros(N, np.int32), r, v)
+        e.rebin(); e.halo(); e.forces(0)
+        if mode != "piecewise":
+            res = e.run(dt, nsteps)
+        else:
+            e.kick_drift(dt)
+            for s in range(nsteps):
+                e.rebin(); e.halo()
+                if s + 1 < nsteps:
+                    if s % 2:
+                        e.forces_kick_drift(0, dt)
+                    else:  # overlap split
+                        e.forces_kick_drift(1, dt)
+                        with pytest.raises(capi.Ls1HipError):
+                            e.forces(2)  # a fused inner pass must be completed by a fused boundary pass
+                        e.forces_kick_drift(2, dt)
+                    with pytest.raises(capi.Ls1HipError):
+                        e.download_forces()  # F was consumed
+                    with pytest.raises(capi.Ls1HipError):
+                        e.kick_drift(dt)  # already advanced
+                    if s == 2:
+                        st_mid = e.download_state()  # materialises the advanced positions; the loop must go on unharmed
+                        assert np.all(np.isfinite(st_mid["r"]))
+                else:
+                    u, w = e.forces(0)
+            k = e.kick(0.5 * dt)
+            res = dict(upot=u, virial=w, summv2=k[0])
+        st = e.download_state()
+        o = np.argsort(st["ids"])
+        out[mode] = (st["r"][o], st["v"][o], e.download_forces()["F"][o], res["upot"], res["virial"], res["summv2"])
+        e.close()
+    for mode in ("fused", "piecewise"):
+        for a, b in zip(out["unfused"][:3], out[mode][:3]):
+            assert np.array_equal(a, b), mode
+        # macroscopic sums: the which=1/2 split adds partial sums in a different order (rounding only)
+        tol = 0.0 if mode == "fused" else 1e-13
+        for a, b in zip(out["unfused"][3:], out[mode][3:]):
+            assert abs(a - b) <= tol * abs(a), mode
+
+
 def test_inner_outer_split_equals_full_traversal():
     """traversePartialInnermostCells + traverseNonInnermostCells == traverseCells (LinkedCellsTest.cpp:239-280)."""
     case = MAN["bcc1clj_16000"]

@@ -28,7 +28,9 @@ summary = {"source": "tools/collect_profiles.sh (rocprofv3 --pmc, one pass per c
                      "bench.py " + " ".join(bench_args) + ", per-launch means",
            "units": {"FETCH_SIZE": "KB as reported", "WRITE_SIZE": "KB as reported", "SQ_*_CYCLES": "quad-cycles"},
            "molecules": n, "kernels": kern}
-kd = [k for k in kern if "k_kick_then_kick_drift" in k]
+# calibration kernel with exactly known traffic (72 B read, 48 B written per molecule): the fused kick pair, or — when
+# the force pass does the integration itself — the plain kick+drift pass of the first step
+kd = [k for k in kern if "k_kick_then_kick_drift" in k] or [k for k in kern if "k_kick_drift" in k]
 if kd and "FETCH_SIZE" in kern[kd[0]]:
     k = kern[kd[0]]
     summary["calibration"] = {"kernel": kd[0], "known_read_bytes": 72.0 * n, "known_write_bytes": 48.0 * n,

@@ -54,8 +54,50 @@ __device__ __forceinline__ bool cell_is_innermost(const Grid& g, int cx, int cy,
 	return cx >= lo && cy >= lo && cz >= lo && cx < g.dims[0] - lo && cy < g.dims[1] - lo && cz < g.dims[2] - lo;
 }
 
+// Evaluate everything molecule j does to molecule i (centre distance already tested: dd < rc2, dd != 0).
+template <bool ONE_CLJ, bool WITH_VI, bool HAS_ROT>
+__device__ __forceinline__ void generic_pair(const ForceParams& P, int ci, const V3& ri, const Rot& Ri, uint32_t j, const V3& rj,
+											  const V3& drm, double dd, double rclj2, MolAcc& acc) {
+	if (ONE_CLJ) {
+		if (dd < rclj2) {
+			V3 f;
+			double u;
+			lj(drm, dd, P.eps24, P.sig2, f, u);
+			acc.F = acc.F + f;
+			acc.u6 += 0.5 * (u + P.shift6);
+			acc.vir += 0.5 * dot(drm, f);
+			if (WITH_VI) {
+				acc.Vi.x += 0.5 * drm.x * f.x;
+				acc.Vi.y += 0.5 * drm.y * f.y;
+				acc.Vi.z += 0.5 * drm.z * f.z;
+			}
+		}
+	} else {
+		const int cj = P.cid[j];
+		Rot Rj;
+		if (HAS_ROT) {
+			double w = P.q0[j], x = P.q1[j], y = P.q2[j], z = P.q3[j];
+			const double inv = 1. / sqrt(w * w + x * x + y * y + z * z);
+			Rj = rot_of(w * inv, x * inv, y * inv, z * inv);
+		} else {
+			Rj = rot_of(1., 0., 0., 0.);
+		}
+		mol_pair<WITH_VI>(*P.ct, ci, ri, Ri, cj, rj, Rj, drm, dd < rclj2, 0.5, acc);
+	}
+}
+
+// One lane per owned molecule, any component set.  Two phases, as in the LJ fast path: the (cheap) centre-distance test
+// over the (2hw+1)^3 neighbour cells appends the in-range j to a per-lane list in LDS; the (expensive) molecule-pair
+// body — up to 16 x 16 site interactions with on-the-fly rotations — then runs over the list with every lane busy.
+// Evaluating the body inside the search loop made the whole wave execute it whenever ANY lane had a hit, i.e. almost
+// every iteration at ~15 % useful lanes (measured: ethane 9.8 M molecules 18.5 ms -> see DESIGN.md).  The list keeps the
+// candidate order, so the sums are bitwise those of the single loop.  A lane whose list overflows re-scans directly.
+constexpr int GCAP = 79;  // list entries per lane: (GCAP + 1) x 128 x 4 B = 40 KB -> 4 workgroups (8 waves) / CU, the VGPR limit of the multi-site body
 template <bool ONE_CLJ, bool WITH_VI, bool HAS_ROT>
 __global__ void __launch_bounds__(FTPB) k_force_generic(ForceParams P) {
+	// slot-major; row GCAP = dummy target of misses / overflow.  The single-centre LJ body is as cheap as the list
+	// bookkeeping (measured 5.5 -> 10.5 ms with a list), so ONE_CLJ keeps the single loop and no LDS.
+	__shared__ uint32_t glist[ONE_CLJ ? 1 : (GCAP + 1) * FTPB];
 	const uint32_t p = blockIdx.x * FTPB + threadIdx.x;
 	const uint32_t n_real = P.n_fixed ? P.n_fixed : P.cnt->n_real;
 	bool active = p < n_real;
@@ -93,47 +135,50 @@ __global__ void __launch_bounds__(FTPB) k_force_generic(ForceParams P) {
 		const double rc2 = ONE_CLJ ? P.rc2 : P.ct->rc2;
 		const double rclj2 = ONE_CLJ ? P.rc2 : P.ct->rclj2;
 		const int hw = P.g.hw;
-		for (int dz = -hw; dz <= hw; ++dz)
+		// ---- phase 1: candidate search ---------------------------------------------------------------------------------
+		uint32_t cnt = 0;
+		uint32_t* const mylist = glist + threadIdx.x;
+		for (int dz = -hw; dz <= hw && !ONE_CLJ; ++dz)
 			for (int dy = -hw; dy <= hw; ++dy)
 				for (int dx = -hw; dx <= hw; ++dx) {
 					const int c2 = cell_index(P.g, cx + dx, cy + dy, cz + dz);
 					const uint32_t jb = P.cell_begin[c2], je = P.cell_end[c2];
 					for (uint32_t j = jb; j < je; ++j) {
-						if (j == p) continue;
-						const V3 rj = {P.x[j], P.y[j], P.z[j]};
-						const V3 drm = ri - rj;
-						const double dd = dot(drm, drm);
+						const double ex = ri.x - P.x[j], ey = ri.y - P.y[j], ez = ri.z - P.z[j];
+						const double dd = ex * ex + ey * ey + ez * ez;
+						const bool hit = (dd < rc2) & (dd != 0.) & (j != p);
+						mylist[(hit ? min(cnt, (uint32_t)GCAP) : (uint32_t)GCAP) * FTPB] = j;
+						cnt += hit ? 1u : 0u;
 						++nchk;
-						if (!(dd < rc2) || dd == 0.) continue;
-						++nhit;
-						if (ONE_CLJ) {
-							if (dd < rclj2) {
-								V3 f;
-								double u;
-								lj(drm, dd, P.eps24, P.sig2, f, u);
-								acc.F = acc.F + f;
-								acc.u6 += 0.5 * (u + P.shift6);
-								acc.vir += 0.5 * dot(drm, f);
-								if (WITH_VI) {
-									acc.Vi.x += 0.5 * drm.x * f.x;
-									acc.Vi.y += 0.5 * drm.y * f.y;
-									acc.Vi.z += 0.5 * drm.z * f.z;
-								}
-							}
-						} else {
-							const int cj = P.cid[j];
-							Rot Rj;
-							if (HAS_ROT) {
-								double w = P.q0[j], x = P.q1[j], y = P.q2[j], z = P.q3[j];
-								const double inv = 1. / sqrt(w * w + x * x + y * y + z * z);
-								Rj = rot_of(w * inv, x * inv, y * inv, z * inv);
-							} else {
-								Rj = rot_of(1., 0., 0., 0.);
-							}
-							mol_pair<WITH_VI>(*P.ct, ci, ri, Ri, cj, rj, Rj, drm, dd < rclj2, 0.5, acc);
-						}
 					}
 				}
+		nhit = cnt;
+		// ---- phase 2: molecule-pair bodies over the list ---------------------------------------------------------------
+		if (!ONE_CLJ && cnt <= (uint32_t)GCAP) {
+			for (uint32_t s = 0; s < cnt; ++s) {
+				const uint32_t j = mylist[s * FTPB];
+				const V3 rj = {P.x[j], P.y[j], P.z[j]};
+				const V3 drm = ri - rj;
+				generic_pair<ONE_CLJ, WITH_VI, HAS_ROT>(P, ci, ri, Ri, j, rj, drm, dot(drm, drm), rclj2, acc);
+			}
+		} else {
+			for (int dz = -hw; dz <= hw; ++dz)
+				for (int dy = -hw; dy <= hw; ++dy)
+					for (int dx = -hw; dx <= hw; ++dx) {
+						const int c2 = cell_index(P.g, cx + dx, cy + dy, cz + dz);
+						const uint32_t jb = P.cell_begin[c2], je = P.cell_end[c2];
+						for (uint32_t j = jb; j < je; ++j) {
+							if (j == p) continue;
+							const V3 rj = {P.x[j], P.y[j], P.z[j]};
+							const V3 drm = ri - rj;
+							const double dd = dot(drm, drm);
+							if (ONE_CLJ) ++nchk;
+							if (!(dd < rc2) || dd == 0.) continue;
+							if (ONE_CLJ) ++nhit;
+							generic_pair<ONE_CLJ, WITH_VI, HAS_ROT>(P, ci, ri, Ri, j, rj, drm, dd, rclj2, acc);
+						}
+					}
+		}
 		P.Fx[p] = acc.F.x;
 		P.Fy[p] = acc.F.y;
 		P.Fz[p] = acc.F.z;

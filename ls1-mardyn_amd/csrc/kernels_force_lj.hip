@@ -1,11 +1,17 @@
-// kernels_force_lj.hip — the MI355X fast path: brick-tiled, LDS-staged single-centre Lennard-Jones force kernel.
+// kernels_force_lj.hip — the MI355X fast path: brick-tiled, LDS-staged single-centre Lennard-Jones force kernels.
+//
+//   k_force_lj_mfma   (default for one cell per cutoff)   FP32 MFMA distance-tile pre-filter + exact FP64 evaluation,
+//                                                         4 lanes per molecule — described at its definition below;
+//   k_force_lj_brick  (cells-in-cutoff 2, very dense cells) FP64 list kernel, 1 or 2 lanes per molecule — described here.
+// Both share the decomposition, the full-shell / no-atomics rule, the XCD-aware brick order, the optional brick lists
+// of the inner / boundary passes and the fused integration epilogue (lj_store).
 //
 // Work decomposition (CDNA4: wave64, 160 KB LDS / CU, FP64 VALU at 4 cycles per wave instruction)
-//   * one 256-thread workgroup per BRICK of BX x BY x BZ cells (about 200 molecules at liquid density);
+//   * one workgroup per BRICK of BX x BY x BZ cells (about 200 molecules at liquid density);
 //   * the brick plus its cutoff shell ((BX+2hw)(BY+2hw)(BZ+2hw) cells, ~1200 molecules) is staged ONCE into LDS
 //     in region-linear order, so every x-row of 2hw+1 neighbour cells is one contiguous LDS range — the
 //     positions of a molecule are read from HBM once per brick instead of once per neighbour;
-//   * one lane per owned molecule i (full shell, no atomics, deterministic):
+//   * list kernel: one lane per owned molecule i (full shell, no atomics, deterministic):
 //       phase 1  walks the (2hw+1)^2 neighbour rows and appends the in-range j to a per-lane list in LDS
 //                (u16 indices, slot-major so lanes hit consecutive banks) — cheap distance arithmetic only;
 //       phase 2  runs the LJ body over the list: every lane of the wave does useful FP64 work in every
@@ -26,10 +32,11 @@
 
 namespace ls1 {
 
-constexpr int LTPB = 256;
-// LDS budget: two workgroups per CU (2 x 80 KB of the 160 KB) = 2 waves per SIMD.
-//   CAPJ  staged molecules per brick region (3 x 8 B each),  CAPL  per-lane neighbour list capacity (u16 each)
-//   hw=1: 1664 x 24 B = 39.9 KB + 72 x 256 x 2 B = 36.9 KB;   hw=2: 1536 x 24 B = 36.9 KB + 64 x 512 B = 32.8 KB (+6.6 KB tables)
+constexpr int LTPB = 256;  // threads per workgroup of the list kernel per SPLIT lane (SPLIT = 2 -> 512 threads)
+// LDS budget of every variant: two workgroups per CU (2 x 80 KB of the 160 KB).
+//   CAPJ  staged molecules per brick region,  CAPL / ROWS  per-lane neighbour list capacity (u16 each)
+//   list kernel, SPLIT = 2, hw = 1:  1616 x 24 B = 38.8 KB + 39 rows x 512 x 2 B = 39.9 KB  (4 waves / SIMD)
+//   MFMA kernel, 512 threads:        1712 x 28 B = 47.9 KB + 32 rows x 512 x 2 B = 32.8 KB  (4 waves / SIMD)
 
 __device__ __forceinline__ double fast_rcp(double d) {
 	double x = __builtin_amdgcn_rcp(d);

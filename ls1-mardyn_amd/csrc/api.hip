@@ -712,15 +712,17 @@ static int launch_forces(ls1hip_ctx* c, int which, bool fuse = false, double dt 
 	uint32_t nblocks = 0;
 	if (which == 0 || which == 1) launch_clear_macro(c->d_cnt, c->stream);
 	bool done = false;
+	const double ncell = (double)c->g.box[0] * c->g.box[1] * c->g.box[2];
+	const double mean_per_cell = ncell > 0 ? (double)c->n_real / ncell : 0.;
 	if (c->one_clj && c->opt_force_kernel != LS1HIP_FK_GENERIC && !c->opt_vi && !c->opt_count_pairs) {
-		const double ncell = (double)c->g.box[0] * c->g.box[1] * c->g.box[2];
-		done = launch_force_lj(P, c->stream, &nblocks, c->d_partials, c->partials_cap, (int)c->opt_lj_split,
-							   ncell > 0 ? (double)c->n_real / ncell : 0., &c->brick_lists);
+		done = launch_force_lj(P, c->stream, &nblocks, c->d_partials, c->partials_cap, (int)c->opt_lj_split, mean_per_cell,
+							   &c->brick_lists);
+	} else if (!c->one_clj && c->opt_force_kernel != LS1HIP_FK_GENERIC && !c->opt_count_pairs && which != 3) {
+		done = launch_force_ms(P, c->opt_vi != 0, c->h_ct.has_rot != 0, c->stream, &nblocks, c->partials_cap, mean_per_cell,
+							   &c->brick_lists);
 	}
 	if (!done && fuse) FAIL(c, LS1HIP_EINVAL, "fused force + integration needs the single-centre LJ fast path");
 	if (!done) {
-		if (c->opt_force_kernel == LS1HIP_FK_LDS_LIST && !c->one_clj)
-			FAIL(c, LS1HIP_EINVAL, "force_kernel=LDS_LIST supports single-centre LJ components only");
 		launch_force_generic(P, c->one_clj, c->opt_vi != 0, c->h_ct.has_rot != 0, c->stream, &nblocks);
 	}
 	launch_force_reduce(c->d_cnt, c->d_partials, nblocks, c->d_stage, c->stream);

@@ -198,6 +198,9 @@ void launch_force_generic(const ForceParams& p, bool one_clj, bool with_vi, bool
 // LDS-tiled 1CLJ kernel (kernels_force_lj.hip); returns false if it cannot handle the configuration
 bool launch_force_lj(const ForceParams& p, hipStream_t s, uint32_t* nblocks, double* partials, size_t partials_cap,
 					 int split, double mean_per_cell, BrickLists* bl);
+// brick-tiled multi-site kernel (kernels_force_ms.hip); returns false if it cannot handle the configuration
+bool launch_force_ms(const ForceParams& p, bool with_vi, bool has_rot, hipStream_t s, uint32_t* nblocks, size_t partials_cap,
+					 double mean_per_cell, BrickLists* bl);
 void launch_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, double* stage, hipStream_t s);
 void launch_clear_macro(DevCounters* cnt, hipStream_t s);
 

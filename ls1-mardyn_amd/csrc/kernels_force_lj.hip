@@ -26,6 +26,7 @@
 // SIMD_VectorizedCellProcessorHelpers.h:344-422); the reciprocal is v_rcp_f64 + 2 Newton steps (the reference's
 // own AVX2 path is rcp_ps + 3 Newton steps, RealVecDouble.h:415-434) — parity is tolerance-based (1e-10).
 #include "common.hpp"
+#include "brick.hpp"
 
 #include <algorithm>
 #include <vector>
@@ -120,38 +121,6 @@ __device__ __forceinline__ void lj_store(const ForceParams& P, uint32_t gi, cons
 __device__ __forceinline__ double wave_sum_lj(double v) {
 	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
 	return v;
-}
-
-// block-wide exclusive scan of `n` (<= LTPB*4) u32 values held in LDS array v[0..n) -> v becomes exclusive prefix,
-// v[n] = total.  All threads must call.
-template <int NT>
-__device__ __forceinline__ void block_scan_lds(uint32_t* v, int n, uint32_t* wsum) {
-	const int t = threadIdx.x;
-	uint32_t a[4], s = 0;
-	for (int k = 0; k < 4; ++k) {
-		const int i = t * 4 + k;
-		a[k] = (i < n) ? v[i] : 0u;
-		s += a[k];
-	}
-	uint32_t inc = s;
-	const int lane = t & 63, w = t >> 6;
-	for (int o = 1; o < 64; o <<= 1) {
-		const uint32_t u = __shfl_up(inc, o);
-		if (lane >= o) inc += u;
-	}
-	if (lane == 63) wsum[w] = inc;
-	__syncthreads();
-	uint32_t base = 0;
-	for (int i = 0; i < w; ++i) base += wsum[i];
-	uint32_t ex = base + inc - s;
-	__syncthreads();
-	for (int k = 0; k < 4; ++k) {
-		const int i = t * 4 + k;
-		if (i < n) v[i] = ex;
-		ex += a[k];
-	}
-	if (t == NT - 1) v[n] = ex;  // last thread's running value = total (its items beyond n contribute 0)
-	__syncthreads();
 }
 
 template <int HW, int BX, int BY, int BZ, int CAPJ, int CAPL, int SPLIT>
@@ -755,7 +724,7 @@ static bool brick_lists_for(BrickLists* bl, const Grid& g, int BX, int BY, int B
 }
 
 // number of workgroups for a traversal; fills p.brick_list / p.n_list for the inner (1) / boundary (2) passes
-static long plan_bricks(ForceParams& p, BrickLists* bl, int BX, int BY, int BZ, int nbx, int nby, int nbz) {
+long plan_bricks(ForceParams& p, BrickLists* bl, int BX, int BY, int BZ, int nbx, int nby, int nbz) {
 	long n = (long)nbx * nby * nbz;
 	p.brick_list = nullptr;
 	p.n_list = 0;

@@ -1,0 +1,292 @@
+// kernels_force_ms.hip — brick-tiled, LDS-staged force kernel for ANY component set (multi-centre LJ, charges, dipoles,
+// quadrupoles): the multi-site counterpart of k_force_lj_brick.
+//
+//   * one 256-thread workgroup per brick of BX x BY x BZ cells; the brick and its cutoff shell are staged ONCE into LDS
+//     in region-linear order: centre position (FP64 x, y, z), NORMALISED quaternion (FullMolecule::setupSoACache
+//     normalises q before rotating, FullMolecule.cpp:720 — done once per staged molecule here instead of once per pair)
+//     and component id (u8): 57 B per molecule, every x-row of 3 neighbour cells is one contiguous LDS range;
+//   * one lane per owned molecule, lanes enumerate the brick's molecules densely (no per-cell tiles: the multi-site
+//     fixtures have 2-4 molecules per cell), full shell, no atomics, deterministic;
+//   * phase 1: centre-distance test over the 9 neighbour rows (LJ and electrostatics both cut on the CENTRE distance,
+//     VectorizedCellProcessor.cpp:967-968,1013-1024), in-range j appended branch-free to a per-lane u16 list in LDS;
+//   * phase 2: the molecule-pair body (mol_pair: all ten site-type combinations with on-the-fly site rotation, torque and
+//     per-molecule virial) over the list, every lane busy.  Candidates are visited in the order of the generic kernel
+//     (dz, dy, then x), so forces, torques and sums are bitwise those of k_force_generic;
+//   * list overflow and shells larger than the staging area fall back to direct evaluation (same arithmetic).
+// Against k_force_generic (neighbours fetched by every lane from global memory: 27 dependent, uncoalesced cell walks per
+// molecule) positions arrive coalesced once per brick and the search runs out of LDS.
+#include "common.hpp"
+#include "brick.hpp"
+
+namespace ls1 {
+
+constexpr int MTPB = 256;
+
+// 4-double block reduction -> partials[blockIdx.x][4]
+__device__ __forceinline__ void ms_block_reduce4(double v0, double v1, double v2, double v3, double* partials, double (*red)[4]) {
+	double v[4] = {v0, v1, v2, v3};
+	for (int k = 0; k < 4; ++k)
+		for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o);
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	if (lane == 0)
+		for (int k = 0; k < 4; ++k) red[w][k] = v[k];
+	__syncthreads();
+	if (threadIdx.x < 4) {
+		double s = 0.;
+		for (int i = 0; i < MTPB / 64; ++i) s += red[i][threadIdx.x];
+		partials[(size_t)blockIdx.x * 4 + threadIdx.x] = s;
+	}
+}
+
+template <int BX, int BY, int BZ, int CAPJ, int CAPL, bool WITH_VI, bool HAS_ROT>
+__global__ void __launch_bounds__(MTPB) k_force_ms_brick(ForceParams P, int nbx, int nby, int nbz) {
+	constexpr int HW = 1, NT = MTPB;
+	constexpr int RX = BX + 2 * HW, RY = BY + 2 * HW, RZ = BZ + 2 * HW;
+	constexpr int NRC = RX * RY * RZ;
+	constexpr int NBC = BX * BY * BZ;
+	constexpr int NW = 3, NROWS = 9;
+	constexpr int QN = HAS_ROT ? CAPJ : 1;
+	static_assert(NRC <= NT * 4 && NBC <= NT * 4, "region too large for the block scan");
+	__shared__ double sx[CAPJ], sy[CAPJ], sz[CAPJ];
+	__shared__ double sq0[QN], sq1[QN], sq2[QN], sq3[QN];  // normalised quaternion
+	__shared__ uint8_t scid[CAPJ];
+	__shared__ uint16_t lst[(CAPL + 1) * NT];  // slot-major; row CAPL = dummy target of misses / overflow
+	__shared__ uint32_t cstart[NRC + 1];
+	__shared__ uint32_t gbeg[NRC];
+	__shared__ uint32_t bstart[NBC + 1];
+	__shared__ uint32_t wsum[NT / 64];
+	__shared__ double red[NT / 64][4];
+
+	const int tid = threadIdx.x;
+	const int nb = P.brick_list ? (int)P.n_list : nbx * nby * nbz;
+	const int chunk = gridDim.x / 8;
+	const int slot = (blockIdx.x % 8) * chunk + blockIdx.x / 8;  // XCD-aware brick order (see k_force_lj_brick)
+	bool live = slot < nb;
+	const int brick = (live && P.brick_list) ? (int)P.brick_list[slot] : slot;
+	int bx = 0, by = 0, bz = 0;
+	if (live) {
+		bx = brick % nbx;
+		by = (brick / nbx) % nby;
+		bz = brick / (nbx * nby);
+	}
+	const int x0 = HW + bx * BX, y0 = HW + by * BY, z0 = HW + bz * BZ;
+	const int ex = min(BX, P.g.dims[0] - HW - x0), ey = min(BY, P.g.dims[1] - HW - y0), ez = min(BZ, P.g.dims[2] - HW - z0);
+	if (live && P.which != 0 && !P.brick_list) {
+		const bool inner = x0 >= 2 * HW && y0 >= 2 * HW && z0 >= 2 * HW && x0 + ex <= P.g.dims[0] - 2 * HW &&
+						   y0 + ey <= P.g.dims[1] - 2 * HW && z0 + ez <= P.g.dims[2] - 2 * HW;
+		live = (P.which == 1) ? inner : !inner;
+	}
+	if (!live) {
+		if (tid < 4) P.partials[(size_t)blockIdx.x * 4 + tid] = 0.;
+		return;
+	}
+	// ---- region cell table, brick cell prefix --------------------------------------------------------------------------
+	for (int c = tid; c < NRC; c += NT) {
+		const int rx = c % RX, ry = (c / RX) % RY, rz = c / (RX * RY);
+		const int gx = x0 - HW + rx, gy = y0 - HW + ry, gz = z0 - HW + rz;
+		uint32_t b = 0, n = 0;
+		if (gx < P.g.dims[0] && gy < P.g.dims[1] && gz < P.g.dims[2]) {
+			const int gc = cell_index(P.g, gx, gy, gz);
+			b = P.cell_begin[gc];
+			n = P.cell_end[gc] - b;
+		}
+		gbeg[c] = b;
+		cstart[c] = n;
+	}
+	__syncthreads();
+	block_scan_lds<NT>(cstart, NRC, wsum);
+	const uint32_t total = cstart[NRC];
+	for (int c = tid; c < NBC; c += NT) {
+		const int cx = c % BX, cy = (c / BX) % BY, cz = c / (BX * BY);
+		uint32_t n = 0;
+		if (cx < ex && cy < ey && cz < ez) {
+			const int rcell = ((cz + HW) * RY + (cy + HW)) * RX + (cx + HW);
+			n = cstart[rcell + 1] - cstart[rcell];
+		}
+		bstart[c] = n;
+	}
+	__syncthreads();
+	block_scan_lds<NT>(bstart, NBC, wsum);
+	const uint32_t n_i = bstart[NBC];
+	const bool staged = total <= (uint32_t)CAPJ;
+	// ---- stage centres, normalised quaternions, component ids --------------------------------------------------------
+	if (staged) {
+		for (uint32_t s = tid; s < total; s += NT) {
+			int lo = 0, hi = NRC;
+			while (hi - lo > 1) {
+				const int mid = (lo + hi) >> 1;
+				if (cstart[mid] <= s) lo = mid;
+				else hi = mid;
+			}
+			const uint32_t g = gbeg[lo] + (s - cstart[lo]);
+			sx[s] = P.x[g];
+			sy[s] = P.y[g];
+			sz[s] = P.z[g];
+			scid[s] = (uint8_t)P.cid[g];
+			if (HAS_ROT) {
+				const double w = P.q0[g], x = P.q1[g], y = P.q2[g], z = P.q3[g];
+				const double inv = 1. / sqrt(w * w + x * x + y * y + z * z);
+				sq0[s] = w * inv;
+				sq1[s] = x * inv;
+				sq2[s] = y * inv;
+				sq3[s] = z * inv;
+			}
+		}
+	}
+	__syncthreads();
+
+	const double rc2 = P.ct->rc2, rclj2 = P.ct->rclj2;
+	double u6_t = 0., uX_t = 0., rf_t = 0., vir_t = 0.;
+	uint16_t* const mylist = lst + tid;
+	for (uint32_t base = 0; base < n_i; base += NT) {  // one pass unless the brick holds more than 256 molecules
+		const uint32_t it = base + (uint32_t)tid;
+		if (it >= n_i) continue;
+		int lo = 0, hi = NBC;
+		while (hi - lo > 1) {
+			const int mid = (lo + hi) >> 1;
+			if (bstart[mid] <= it) lo = mid;
+			else hi = mid;
+		}
+		const int cx = lo % BX, cy = (lo / BX) % BY, cz = lo / (BX * BY);
+		const int rcell = ((cz + HW) * RY + (cy + HW)) * RX + (cx + HW);
+		const uint32_t k = it - bstart[lo];
+		const uint32_t ii = cstart[rcell] + k;
+		const uint32_t gi = gbeg[rcell] + k;
+		const int rowbase = (cz * RY + cy) * RX + cx;  // first cell of row 0 of the neighbourhood
+		MolAcc acc;
+		acc.F = {0., 0., 0.};
+		acc.M = {0., 0., 0.};
+		acc.Vi = {0., 0., 0.};
+		acc.u6 = acc.uX = acc.rf = acc.vir = 0.;
+		if (staged) {
+			const V3 ri = {sx[ii], sy[ii], sz[ii]};
+			const int ci = scid[ii];
+			const Rot Ri = HAS_ROT ? rot_of(sq0[ii], sq1[ii], sq2[ii], sq3[ii]) : rot_of(1., 0., 0., 0.);
+			auto pair = [&](uint32_t j) {  // candidate j (LDS index): exact test done by the caller
+				const V3 rj = {sx[j], sy[j], sz[j]};
+				const V3 drm = ri - rj;
+				const Rot Rj = HAS_ROT ? rot_of(sq0[j], sq1[j], sq2[j], sq3[j]) : rot_of(1., 0., 0., 0.);
+				mol_pair<WITH_VI>(*P.ct, ci, ri, Ri, (int)scid[j], rj, Rj, drm, dot(drm, drm) < rclj2, 0.5, acc);
+			};
+			// ---- phase 1 ---------------------------------------------------------------------------------------------------
+			uint32_t cnt = 0;
+			for (int row = 0; row < NROWS; ++row) {
+				const int r0 = rowbase + (row / NW) * (RY * RX) + (row % NW) * RX;
+				const uint32_t jb = cstart[r0], je = cstart[r0 + NW];
+				for (uint32_t j = jb; j < je; ++j) {
+					const double dx = ri.x - sx[j], dy = ri.y - sy[j], dz = ri.z - sz[j];
+					const double dd = dx * dx + dy * dy + dz * dz;
+					const bool hit = (dd < rc2) & (dd != 0.);  // dd == 0: the molecule itself
+					mylist[(hit ? min(cnt, (uint32_t)CAPL) : (uint32_t)CAPL) * NT] = (uint16_t)j;
+					cnt += hit ? 1u : 0u;
+				}
+			}
+			// ---- phase 2 ---------------------------------------------------------------------------------------------------
+			if (cnt <= (uint32_t)CAPL) {
+				for (uint32_t s = 0; s < cnt; ++s) pair(mylist[s * NT]);
+			} else {
+				for (int row = 0; row < NROWS; ++row) {
+					const int r0 = rowbase + (row / NW) * (RY * RX) + (row % NW) * RX;
+					const uint32_t jb = cstart[r0], je = cstart[r0 + NW];
+					for (uint32_t j = jb; j < je; ++j) {
+						const double dx = ri.x - sx[j], dy = ri.y - sy[j], dz = ri.z - sz[j];
+						const double dd = dx * dx + dy * dy + dz * dz;
+						if ((dd < rc2) & (dd != 0.)) pair(j);
+					}
+				}
+			}
+		} else {
+			// shell does not fit the staging area: same walk straight from global memory
+			const V3 ri = {P.x[gi], P.y[gi], P.z[gi]};
+			const int ci = P.cid[gi];
+			Rot Ri = rot_of(1., 0., 0., 0.);
+			if (HAS_ROT) {
+				const double w = P.q0[gi], x = P.q1[gi], y = P.q2[gi], z = P.q3[gi];
+				const double inv = 1. / sqrt(w * w + x * x + y * y + z * z);
+				Ri = rot_of(w * inv, x * inv, y * inv, z * inv);
+			}
+			for (int row = 0; row < NROWS; ++row) {
+				const int r0 = rowbase + (row / NW) * (RY * RX) + (row % NW) * RX;
+				for (int c = r0; c < r0 + NW; ++c) {
+					const uint32_t g0 = gbeg[c], n = cstart[c + 1] - cstart[c];
+					for (uint32_t j = g0; j < g0 + n; ++j) {
+						if (j == gi) continue;
+						const V3 rj = {P.x[j], P.y[j], P.z[j]};
+						const V3 drm = ri - rj;
+						const double dd = dot(drm, drm);
+						if (!(dd < rc2) || dd == 0.) continue;
+						Rot Rj = rot_of(1., 0., 0., 0.);
+						if (HAS_ROT) {
+							const double w = P.q0[j], x = P.q1[j], y = P.q2[j], z = P.q3[j];
+							const double inv = 1. / sqrt(w * w + x * x + y * y + z * z);
+							Rj = rot_of(w * inv, x * inv, y * inv, z * inv);
+						}
+						mol_pair<WITH_VI>(*P.ct, ci, ri, Ri, P.cid[j], rj, Rj, drm, dd < rclj2, 0.5, acc);
+					}
+				}
+			}
+		}
+		P.Fx[gi] = acc.F.x;
+		P.Fy[gi] = acc.F.y;
+		P.Fz[gi] = acc.F.z;
+		if (HAS_ROT) {
+			P.Mx[gi] = acc.M.x;
+			P.My[gi] = acc.M.y;
+			P.Mz[gi] = acc.M.z;
+		}
+		if (WITH_VI) {
+			P.Vix[gi] = acc.Vi.x;
+			P.Viy[gi] = acc.Vi.y;
+			P.Viz[gi] = acc.Vi.z;
+		}
+		u6_t += acc.u6;
+		uX_t += acc.uX;
+		rf_t += acc.rf;
+		vir_t += acc.vir;
+	}
+	ms_block_reduce4(u6_t, uX_t, rf_t, vir_t, P.partials, red);
+}
+
+template <int BX, int BY, int BZ, int CAPJ_ROT, int CAPJ_NOROT, int CAPL>
+static bool launch_ms(ForceParams p, BrickLists* bl, bool with_vi, bool has_rot, hipStream_t s, uint32_t* nblocks,
+					  size_t partials_cap) {
+	const Grid& g = p.g;
+	const int nbx = (g.box[0] + BX - 1) / BX, nby = (g.box[1] + BY - 1) / BY, nbz = (g.box[2] + BZ - 1) / BZ;
+	if ((long)nbx * nby * nbz <= 0 || (long)nbx * nby * nbz > 0x7ffffff0L) return false;
+	const long nb = plan_bricks(p, bl, BX, BY, BZ, nbx, nby, nbz);
+	if ((size_t)nb > partials_cap) return false;
+	*nblocks = (uint32_t)nb;
+	if (nb == 0) return true;
+	const dim3 grid((uint32_t)nb), block(MTPB);
+	if (has_rot) {
+		if (with_vi) hipLaunchKernelGGL((k_force_ms_brick<BX, BY, BZ, CAPJ_ROT, CAPL, true, true>), grid, block, 0, s, p, nbx, nby, nbz);
+		else hipLaunchKernelGGL((k_force_ms_brick<BX, BY, BZ, CAPJ_ROT, CAPL, false, true>), grid, block, 0, s, p, nbx, nby, nbz);
+	} else {
+		if (with_vi) hipLaunchKernelGGL((k_force_ms_brick<BX, BY, BZ, CAPJ_NOROT, CAPL, true, false>), grid, block, 0, s, p, nbx, nby, nbz);
+		else hipLaunchKernelGGL((k_force_ms_brick<BX, BY, BZ, CAPJ_NOROT, CAPL, false, false>), grid, block, 0, s, p, nbx, nby, nbz);
+	}
+	return true;
+}
+
+// LDS budget 80 KB per workgroup (2 per CU = 2 waves / SIMD, the occupancy the ~220-VGPR pair body allows anyway).
+// Staging costs 57 B / molecule with quaternions, 25 B without; a list row is 256 x 2 B.
+//   sparse variants (<= 4.6 molecules / cell): 31 list rows (16 KB), CAPJ 1080 / 2470
+//   dense  variants:                           63 list rows (32 KB), CAPJ  800 / 1800
+// The brick must also hold about 256 owned molecules: with two 80 KB workgroups per CU, idle waves are lost occupancy
+// (measured: ethane at 2 molecules per cell in 4x2x2-cell bricks = 32 owned molecules per workgroup ran no faster than
+// the generic kernel).  So the brick shape follows the mean cell occupancy: the largest shape whose shell still fits the
+// staging area with 8 % headroom.  Returns false (-> k_force_generic) when even the smallest brick would overflow.
+bool launch_force_ms(const ForceParams& p, bool with_vi, bool has_rot, hipStream_t s, uint32_t* nblocks, size_t partials_cap,
+					 double mean_per_cell, BrickLists* bl) {
+	if (p.g.hw != 1 || p.ct == nullptr) return false;
+	const double m = mean_per_cell * 1.08;
+	const double cs = has_rot ? 1080. : 2470., cd = has_rot ? 800. : 1800.;
+	if (m * (10 * 6 * 6) <= cs) return launch_ms<8, 4, 4, 1080, 2470, 31>(p, bl, with_vi, has_rot, s, nblocks, partials_cap);
+	if (m * (6 * 6 * 6) <= cs) return launch_ms<4, 4, 4, 1080, 2470, 31>(p, bl, with_vi, has_rot, s, nblocks, partials_cap);
+	if (m * (6 * 6 * 4) <= cd) return launch_ms<4, 4, 2, 800, 1800, 63>(p, bl, with_vi, has_rot, s, nblocks, partials_cap);
+	if (m * (6 * 4 * 4) <= cd) return launch_ms<4, 2, 2, 800, 1800, 63>(p, bl, with_vi, has_rot, s, nblocks, partials_cap);
+	if (m * (4 * 4 * 4) <= cd) return launch_ms<2, 2, 2, 800, 1800, 63>(p, bl, with_vi, has_rot, s, nblocks, partials_cap);
+	return false;
+}
+
+}  // namespace ls1

@@ -500,6 +500,68 @@ def test_lds_kernel_dense_cluster_fallbacks():
         assert abs(lds["upot"] - gen["upot"]) < 1e-12 * abs(gen["upot"])
 
 
+MULTISITE_CASES = [k for k in FORCE_CASES if k not in LJ1_CASES]
+
+
+@pytest.mark.parametrize("name", MULTISITE_CASES)
+def test_multisite_brick_kernel_is_bitwise_the_generic_kernel(name):
+    """k_force_ms_brick (LDS-staged, default for multi-site component sets) visits the candidates in the order of
+    k_force_generic: F, M, Vi bitwise equal, sums to rounding (different partial-sum grouping)."""
+    case = MAN[name]
+    ps = inp.read_inp(input_path(case["input"]))
+    st = sorted_phase_space(ps)
+    gen = run_forces(ps, st, case["rc"], bool(case["periodic"]), kernel=capi.FK_GENERIC)
+    brk = run_forces(ps, st, case["rc"], bool(case["periodic"]), kernel=capi.FK_AUTO)
+    for k in ("F", "M", "Vi"):
+        assert np.array_equal(gen[k], brk[k]), k
+    assert abs(gen["upot"] - brk["upot"]) <= 1e-13 * max(abs(gen["upot"]), 1e-300) + 1e-300
+    assert abs(gen["virial"] - brk["virial"]) <= 1e-13 * max(abs(gen["virial"]), 1e-300) + 1e-300
+
+
+def test_multisite_brick_kernel_fallbacks_and_split():
+    """Ethane-like 2CLJ molecules: (a) liquid-like box against the oracle incl. the inner/boundary split,
+    (b) a dense cluster (list overflow and a shell larger than the staging area) against the generic kernel."""
+    ps0 = inp.read_inp(input_path(MAN["ethan"]["input"]))
+    comps = ps0.components
+    rng = np.random.default_rng(21)
+    # (a) 6000 molecules at 3x the fixture density, random orientations
+    N = 6000
+    L = (N / (3 * 9826 / 571.607759 ** 3)) ** (1 / 3)
+    rc = 32.1254
+    r = rng.uniform(0, L, (N, 3))
+    q = rng.normal(size=(N, 4)); q /= np.linalg.norm(q, axis=1)[:, None]
+    ps = inp.PhaseSpace(comps, np.array([L, L, L]), np.arange(1, N + 1, dtype=np.uint64), np.zeros(N, np.int32),
+                        r, np.zeros((N, 3)), q, np.zeros((N, 3)))
+    st = sorted_phase_space(ps)
+    gen = run_forces(ps, st, rc, True, kernel=capi.FK_GENERIC)
+    brk = run_forces(ps, st, rc, True, kernel=capi.FK_AUTO)
+    for k in ("F", "M", "Vi"):
+        assert np.array_equal(gen[k], brk[k]), k
+    cont = brk["container"]
+    dom = mirror.Domain(ps.length)
+    cp = mirror.VectorizedCellProcessor(dom, rc, rc)
+    cont.traversePartialInnermostCells(cp, 0, 1)
+    cont.traverseNonInnermostCells(cp)
+    mol = cont.molecules()
+    frc = cont.forces()
+    o = np.argsort(mol["ids"])
+    assert np.array_equal(frc["F"][o], brk["F"]) and np.array_equal(frc["M"][o], brk["M"])
+    assert abs(dom.getLocalUpot() - brk["upot"]) <= 1e-13 * abs(brk["upot"])
+    # (b) dense cluster: 1500 molecules inside one cutoff sphere (+ 300 spread out)
+    N = 1800
+    L = 6 * rc
+    r = np.concatenate([rng.uniform(2.2 * rc, 3.0 * rc, (1500, 3)), rng.uniform(0, L, (300, 3))])
+    q = rng.normal(size=(N, 4)); q /= np.linalg.norm(q, axis=1)[:, None]
+    ps = inp.PhaseSpace(comps, np.array([L, L, L]), np.arange(1, N + 1, dtype=np.uint64), np.zeros(N, np.int32),
+                        r, np.zeros((N, 3)), q, np.zeros((N, 3)))
+    st = sorted_phase_space(ps)
+    gen = run_forces(ps, st, rc, True, kernel=capi.FK_GENERIC, vi=False)
+    brk = run_forces(ps, st, rc, True, kernel=capi.FK_AUTO, vi=False)
+    for k in ("F", "M"):
+        assert np.array_equal(gen[k], brk[k]), k
+    assert abs(gen["upot"] - brk["upot"]) <= 1e-12 * abs(gen["upot"])
+
+
 @pytest.mark.parametrize("name", [k for k in FORCE_CASES])
 def test_homogeneous_long_range_correction(name):
     """ls1hip_long_range_homogeneous vs the reference's Homogeneous LRC (golden trailer)."""

@@ -25,13 +25,36 @@ def replicate(ps, k):
     return L * k, r, rep(ps.v), rep(ps.q), rep(ps.D), rep(ps.cid), np.arange(1, n * k ** 3 + 1, dtype=np.uint64)
 
 
+def mixed_bcc(ps, n):
+    """BASELINE configs[4] as SURVEY 8d-5 defines it: the fixture's five components on a jittered bcc lattice at the
+    fixture's number density, component = id mod 5, random unit quaternions."""
+    rng = np.random.default_rng(11)
+    N = 2 * n ** 3
+    rho = 250.0 / 134.266123 ** 3
+    L = (N / rho) ** (1.0 / 3.0)
+    a = L / n
+    g = np.stack(np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij"), -1).reshape(-1, 3) * a
+    r = np.concatenate([g + 0.25 * a, g + 0.75 * a])
+    r = (r + 0.2 * a * rng.uniform(-0.5, 0.5, r.shape)) % L
+    q = rng.normal(size=(N, 4))
+    q /= np.linalg.norm(q, axis=1)[:, None]
+    ncomp = len(ps.components.components)
+    cid = (np.arange(N) % ncomp).astype(np.int32)
+    return np.array([L, L, L]), r, np.zeros((N, 3)), q, np.zeros((N, 3)), cid, np.arange(1, N + 1, dtype=np.uint64)
+
+
 def main():
     name, rc, k = sys.argv[1], float(sys.argv[2]), int(sys.argv[3])
     ps = inp.read_inp(input_path(name))
-    L, r, v, q, D, cid, ids = replicate(ps, k)
+    if len(sys.argv) > 4 and sys.argv[4] == "bcc":
+        L, r, v, q, D, cid, ids = mixed_bcc(ps, k)
+    else:
+        L, r, v, q, D, cid, ids = replicate(ps, k)
     e = engine.DeviceEngine(0)
     e.set_components(ps.components, rc)
     e.set_domain(L)
+    if len(sys.argv) > 5:
+        e.set_option("force_kernel", int(sys.argv[5]))
     e.upload(ids, cid, r, v, q, D)
     e.rebin(); e.halo(); e.forces(0)
     e.timing_enable(True); e.timing_reset()

@@ -239,6 +239,8 @@ def main():
     n_fused = (args.steps - 1) if fused_on else 0  # the last step of a run is unfused (F and kinetic sums are needed)
     alg_bytes_total = n_local * (FUSED_BYTES_PER_MOLECULE * n_fused + FORCE_BYTES_PER_MOLECULE * (args.steps - n_fused))
     alg_bytes_per_launch = alg_bytes_total / max(force_n, 1)
+    # whole step per GPU: plain = force 48 + integrator 120 + re-bin 124 = 292 B; fused = 96 + 124 = 220 B per molecule
+    step_bytes_total = n_local * ((FUSED_BYTES_PER_MOLECULE + 124.0) * n_fused + STEP_BYTES_PER_MOLECULE * (args.steps - n_fused))
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", PMC_SUMMARY)) as fh:
@@ -269,7 +271,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_force_s * 1e3, "launches": int(force_n),
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                         "full_step_frac": STEP_BYTES_PER_MOLECULE * n_total / world * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
+                         "full_step_frac": step_bytes_total / elapsed / 1e9 / HBM_PEAK_GBS},
             "device_ms_per_step": {"force": force_ms / args.steps, "integrate": integ_ms / args.steps,
                                    "rebin": rebin_ms / args.steps, "halo": halo_ms / args.steps},
             "last_step": {k: (float(v_) if not isinstance(v_, int) else v_) for k, v_ in last.items()} if isinstance(last, dict) else None,

@@ -491,31 +491,29 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 	const double oy = P.g.bmin[1] + (double)(y0 - 2 * HW) * P.g.clen[1];
 	const double oz = P.g.bmin[2] + (double)(z0 - 2 * HW) * P.g.clen[2];
 	if (staged) {
-		for (uint32_t s = tid; s < total + PAD; s += NT) {
-			if (s < total) {
-				int lo = 0, hi = NRC;
-				while (hi - lo > 1) {
-					const int mid = (lo + hi) >> 1;
-					if (cstart[mid] <= s) lo = mid;
-					else hi = mid;
-				}
-				const uint32_t g = gbeg[lo] + (s - cstart[lo]);
+		// 16 lanes per region cell (4 cells per wave and trip): no search for the cell of a staged index, and all global
+		// loads of a thread are independent (the per-molecule binary search was a chain of 7 dependent LDS reads)
+		for (int c = tid >> 4; c < NRC; c += NT / 16) {
+			const uint32_t n = cstart[c + 1] - cstart[c], s0 = cstart[c], g0 = gbeg[c];
+			for (uint32_t k = (uint32_t)tid & 15u; k < n; k += 16u) {
+				const uint32_t g = g0 + k, s = s0 + k;
 				const double x = P.x[g], y = P.y[g], z = P.z[g];
 				sx[s] = x;
 				sy[s] = y;
 				sz[s] = z;
 				const float fx = (float)(x - ox), fy = (float)(y - oy), fz = (float)(z - oz);
 				sq[s] = fx * fx + fy * fy + fz * fz;
-			} else {  // padding behind the last molecule: far away, never within the cutoff
-				sx[s] = ox;
-				sy[s] = oy;
-				sz[s] = oz;
-				sq[s] = 3.0e30f;
 			}
+		}
+		if (tid < PAD) {  // padding behind the last molecule: far away, never within the cutoff
+			const uint32_t s = total + (uint32_t)tid;
+			sx[s] = ox;
+			sy[s] = oy;
+			sz[s] = oz;
+			sq[s] = 3.0e30f;
 		}
 	}
 	__syncthreads();
-
 	const double rc2 = P.rc2, eps24 = P.eps24, sig2 = P.sig2, shift6 = P.shift6;
 	// conservative FP32 threshold: |D + |r_j|^2 - r^2| <= ~8 ulp of the largest term (2 E^2, E = region diagonal)
 	const float ext2 = (float)((RX * P.g.clen[0]) * (RX * P.g.clen[0]) + (RY * P.g.clen[1]) * (RY * P.g.clen[1]) +

@@ -426,7 +426,7 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 	constexpr int NBC = BX * BY * BZ;
 	constexpr int NW = NT / 64;
 	constexpr int PLANE = 3 * RX;  // 9 cells of one z-plane of the neighbourhood are contiguous (RX == 3)
-	constexpr int PAD = 32;
+	constexpr int PAD = 48;  // phase 1 prefetches the A operand up to two tiles past the end of a range (index < je + 48)
 	constexpr int CAPS = CAPJ + PAD;
 	constexpr int RSH = (NT == 512) ? 10 : 9;   // list row stride = NT * 2 bytes
 	constexpr uint32_t CAPX = ROWS - 4;          // cnt is clamped to CAPX after every tile; cnt >= CAPX means overflow
@@ -531,10 +531,16 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 	// are fetched with the same two-dword LDS read (4-byte aligned), the k = 3 lanes use the low dword as is.
 	const uint32_t astride = (grp == 3) ? 4u : 8u;
 	const char* const arow = sraw + (size_t)grp * CAPS * 8 + (size_t)jo * astride;
+	typedef uint64_t u64_align4 __attribute__((aligned(4)));  // one ds_read2_b32 for every lane, no branch on grp
 	auto load_a = [&](const char* pa) -> float {
-		const uint32_t lo = reinterpret_cast<const uint32_t*>(pa)[0], hi = reinterpret_cast<const uint32_t*>(pa)[1];
-		const float conv = (float)(__hiloint2double((int)hi, (int)lo) - o_l);
-		return (grp == 3) ? __uint_as_float(lo) : conv;
+		const uint64_t raw = *reinterpret_cast<const u64_align4*>(pa);
+		const float conv = (float)(__longlong_as_double((long long)raw) - o_l);  // meaningless (but harmless) for k = 3
+		return (grp == 3) ? __uint_as_float((uint32_t)raw) : conv;
+	};
+	// cnt += (d < thr): v_cmp + v_addc, kept as a 2-instruction chain (the compiler's version trades a third instruction
+	// per result for a shorter dependency chain, which 4 waves per SIMD hide anyway)
+	auto count_hit = [](uint32_t& cnt, float d, float thr) {
+		asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(cnt) : "v"(d), "v"(thr) : "vcc");
 	};
 	double u6_tot = 0., vir_tot = 0.;
 
@@ -569,24 +575,35 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 					if (jb >= je) continue;  // wave-uniform
 					const char* ap = arow + jb * astride;
 					uint32_t cb8 = (jb + 4u * (uint32_t)grp) * 8u;  // byte offset of this lane's first candidate of the tile
-					float a_next = load_a(ap);
-					uint32_t t = jb;
-					for (; t + 16u < je; t += 16u) {  // full tiles: every candidate is real, no bound test
-						const float a = a_next;
-						ap += 16u * astride;
+					// software pipeline: the MFMA of tile t+1 is issued (and the A operand of tile t+2 loaded) before the
+					// results of tile t are tested, so the matrix-pipe latency (8 passes) and the LDS read overlap the
+					// compare / append work instead of stalling in front of it
+					float a_next = load_a(ap + 16u * astride);
+					floatx4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(load_a(ap), bval, zero, 0, 0, 0);
+					ap += 32u * astride;
+					// The last tile of a range may run past `je` into the next cells of the region.  Normally those are
+					// not neighbour cells of the owned cell (one full cell >= r_c away, or the far-away padding): at worst
+					// the FP32 slack lists one and phase 2 rejects it, so no bound test is needed.  The exception are
+					// ranges followed by fewer than 16 molecules before the NEXT plane's range starts (partial bricks at
+					// the upper domain faces, empty regions): there the overrun would reach true neighbours and list
+					// them twice, so the last tile is tested against `je` (wave-uniform choice).
+					const bool safe = dz == 1 ||
+									  (uint32_t)__builtin_amdgcn_readfirstlane((int)cstart[r0 + RY * RX]) - je >= 16u;
+					const uint32_t je_fast = safe ? je : jb + ((je - jb) & ~15u);
+					for (uint32_t t = jb; t < je_fast; t += 16u) {
+						const floatx4 dn = __builtin_amdgcn_mfma_f32_16x16x4f32(a_next, bval, zero, 0, 0, 0);
 						a_next = load_a(ap);
-						const floatx4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bval, zero, 0, 0, 0);
+						ap += 16u * astride;
 #pragma unroll
 						for (int r = 0; r < 4; ++r) {
 							*reinterpret_cast<uint16_t*>(lst_bytes + ((cnt << RSH) | lane_off)) = (uint16_t)(cb8 + 8u * r);
-							cnt += (d[r] < thr) ? 1u : 0u;
+							count_hit(cnt, d[r], thr);
 						}
 						cnt = min(cnt, CAPX);
 						cb8 += 128u;
+						d = dn;
 					}
-					{  // last (partial) tile of the range
-						const float a = a_next;
-						const floatx4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bval, zero, 0, 0, 0);
+					if (je_fast < je) {  // checked last tile (rare)
 						const uint32_t je8 = je * 8u;
 #pragma unroll
 						for (int r = 0; r < 4; ++r) {
@@ -598,7 +615,8 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 					}
 				}
 				// ---- phase 2: exact FP64 evaluation of the listed pairs (strict mask; self pair has r2 == 0) --------
-				if (valid) {
+				if (P.n_fixed == 8u) { acc.fx = (double)cnt; }  // DEBUG
+				else if (valid) {
 					const double xi = sx[oi], yi = sy[oi], zi = sz[oi];
 					if (cnt < CAPX) {
 						double slj = 0.;
@@ -772,14 +790,14 @@ bool launch_force_lj(const ForceParams& p, hipStream_t s, uint32_t* nblocks, dou
 		// to global memory inside the kernel, so the choice only affects speed
 		split = 2;
 		if (p.g.hw == 1) {
-			if (mean_per_cell * 108. * 1.08 <= 1680.) split = 4;
-			else if (mean_per_cell * 72. * 1.08 <= 1680.) split = 6;
+			if (mean_per_cell * 108. * 1.08 <= 1664.) split = 4;
+			else if (mean_per_cell * 72. * 1.08 <= 1664.) split = 6;
 		}
 	}
 	if (p.g.hw == 1) {
-		if (split == 4) return launch_mfma<512, 4, 4, 1680, 32>(p, bl, s, nblocks, partials_cap);
-		if (split == 5) return launch_mfma<256, 4, 4, 2264, 32>(p, bl, s, nblocks, partials_cap);
-		if (split == 6) return launch_mfma<512, 4, 2, 1680, 32>(p, bl, s, nblocks, partials_cap);
+		if (split == 4) return launch_mfma<512, 4, 4, 1664, 32>(p, bl, s, nblocks, partials_cap);
+		if (split == 5) return launch_mfma<256, 4, 4, 2248, 32>(p, bl, s, nblocks, partials_cap);
+		if (split == 6) return launch_mfma<512, 4, 2, 1664, 32>(p, bl, s, nblocks, partials_cap);
 		if (split == 2) return launch_brick<1, 4, 2, 2, 1616, 38, 2>(p, bl, s, nblocks, partials_cap);
 		return launch_brick<1, 4, 2, 2, 1656, 71, 1>(p, bl, s, nblocks, partials_cap);
 	}

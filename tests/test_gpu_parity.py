@@ -454,10 +454,13 @@ def test_lds_kernel_matches_reference_golden(name, cic, split):
     assert abs(out["virial"] - g["virial"]) <= TOL * max(abs(g["virial"]), 1e-300) or abs(out["virial"] - g["virial"]) < 1e-9
 
 
-def test_lds_kernel_equals_generic_kernel_large_box():
-    """N = 250 000: LDS-list kernel vs the generic kernel (same inputs): forces to 1e-13, sums to 1e-12; also the
-    inner/boundary split and run-to-run bitwise reproducibility of the LDS kernel."""
-    L, r, v = _bcc(50, seed=7)
+@pytest.mark.parametrize("n", [24, 50])
+def test_lds_kernel_equals_generic_kernel_large_box(n):
+    """N = 250 000 (27 cells per dimension) and N = 27 648 (13 cells per dimension: the last brick row of the 4-cell
+    pencil bricks holds ONE cell row — the partial-brick case in which a candidate tile that overruns its range would
+    reach the next plane's neighbour rows): LDS kernels vs the generic kernel (same inputs): forces to 1e-13, sums to
+    1e-12; also the inner/boundary split and run-to-run bitwise reproducibility of the LDS kernels."""
+    L, r, v = _bcc(n, seed=7)
     N = len(r)
     comp = inp.ComponentSet([inp.make_component(lj=[(0, 0, 0, 1, 1, 1, 2.5, 0)])], np.zeros((0, 2)), 1e10)
     ps = inp.PhaseSpace(comp, np.array([L, L, L]), np.arange(1, N + 1, dtype=np.uint64), np.zeros(N, np.int32),

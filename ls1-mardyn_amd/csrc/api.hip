@@ -709,7 +709,6 @@ static int launch_forces(ls1hip_ctx* c, int which, bool fuse = false, double dt 
 		P.dt_inv2m = (.5 * dt) / c->h_ct.mass[0];  // as k_kick_then_kick_drift: dt_halve / mass
 		P.vx = m.vx; P.vy = m.vy; P.vz = m.vz;
 	}
-	if (getenv("LS1_DEBUG_STAGE_ONLY")) P.n_fixed = (uint32_t)atoi(getenv("LS1_DEBUG_STAGE_ONLY"));
 	uint32_t nblocks = 0;
 	if (which == 0 || which == 1) launch_clear_macro(c->d_cnt, c->stream);
 	bool done = false;

@@ -615,8 +615,7 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 					}
 				}
 				// ---- phase 2: exact FP64 evaluation of the listed pairs (strict mask; self pair has r2 == 0) --------
-				if (P.n_fixed == 8u) { acc.fx = (double)cnt; }  // DEBUG
-				else if (valid) {
+				if (valid) {
 					const double xi = sx[oi], yi = sy[oi], zi = sz[oi];
 					if (cnt < CAPX) {
 						double slj = 0.;

@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--no-fuse", action="store_true", help="separate integrator passes instead of the fused force pass")
     ap.add_argument("--decomp", action="store_true",
                     help="diagnostic: run the decomposed (multi-rank) step loop even with one rank")
+    ap.add_argument("--loopback", action="store_true",
+                    help="diagnostic (with --decomp): route the local periodic images through the RCCL transport "
+                         "(send/recv to the own rank): the full multi-GPU exchange path on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -177,7 +180,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         decomp = importlib.import_module("ls1-mardyn_amd.decomp")
         sim = decomp.build_weak_scaling_box(comps, RC, n, world, rank, local_rank, bcc_box, cic=args.cic or None,
-                                            kernel=args.kernel, stage_through_host=rehearse)
+                                            kernel=args.kernel, stage_through_host=rehearse, loopback=args.loopback)
         n_total = sim.n_global
     else:
         engine_mod = importlib.import_module("ls1-mardyn_amd.engine")

@@ -36,7 +36,8 @@ struct TimedScope {
 	ls1hip_ctx* c;
 	Timer* t;
 	hipEvent_t stop = nullptr;
-	TimedScope(ls1hip_ctx* ctx, Timer& tm) : c(ctx), t(&tm) {
+	hipStream_t s;
+	TimedScope(ls1hip_ctx* ctx, Timer& tm, hipStream_t stream = nullptr) : c(ctx), t(&tm), s(stream ? stream : ctx->stream) {
 		if (!c->timing_on) return;
 		if (t->used + 2 > t->ev.size()) {
 			hipEvent_t a, b;
@@ -44,13 +45,13 @@ struct TimedScope {
 			t->ev.push_back(a);
 			t->ev.push_back(b);
 		}
-		hipEventRecord(t->ev[t->used], c->stream);
+		hipEventRecord(t->ev[t->used], s);
 		stop = t->ev[t->used + 1];
 		t->used += 2;
 		t->launches++;
 	}
 	~TimedScope() {
-		if (stop) hipEventRecord(stop, c->stream);
+		if (stop) hipEventRecord(stop, s);
 	}
 };
 
@@ -133,7 +134,12 @@ extern "C" int ls1hip_create(int device, ls1hip_ctx** out) {
 	memset(&c->hs, 0, sizeof(c->hs));
 	memset(&c->h_ct, 0, sizeof(c->h_ct));
 	for (int i = 0; i < 27; ++i) c->nbr[i] = -1;
-	if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess ||
+	int prio_lo = 0, prio_hi = 0;
+	if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+		(e = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi)) != hipSuccess ||
+		(e = hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi)) != hipSuccess ||
+		(e = hipEventCreateWithFlags(&c->ev_owned, hipEventDisableTiming)) != hipSuccess ||
+		(e = hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming)) != hipSuccess ||
 		(e = hipMalloc((void**)&c->d_ct, sizeof(CompTable))) != hipSuccess ||
 		(e = hipMalloc((void**)&c->d_cnt, sizeof(DevCounters))) != hipSuccess ||
 		(e = hipMalloc((void**)&c->d_stage, 128 * 4 * sizeof(double))) != hipSuccess ||
@@ -160,6 +166,9 @@ extern "C" int ls1hip_destroy(ls1hip_ctx* c) {
 	if (c->h_cnt) hipHostFree(c->h_cnt);
 	timer_free(c->t_force); timer_free(c->t_integrate); timer_free(c->t_rebin); timer_free(c->t_halo);
 	hipStreamDestroy(c->stream);
+	if (c->stream2) hipStreamDestroy(c->stream2);
+	if (c->ev_owned) hipEventDestroy(c->ev_owned);
+	if (c->ev_halo) hipEventDestroy(c->ev_halo);
 	delete c;
 	return LS1HIP_OK;
 }
@@ -574,9 +583,13 @@ extern "C" int ls1hip_upload(ls1hip_ctx* c, size_t n, const uint64_t* id, const 
 	return LS1HIP_OK;
 }
 
-static int sync_counters(ls1hip_ctx* c) {
-	HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->d_cnt, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(c, hipStreamSynchronize(c->stream));
+// stream of the halo phase: the second stream while an inner-cell force pass is in flight on the main one
+static hipStream_t halo_stream(ls1hip_ctx* c) { return c->inner_in_flight ? c->stream2 : c->stream; }
+
+static int sync_counters(ls1hip_ctx* c, hipStream_t s = nullptr) {
+	if (!s) s = c->stream;
+	HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->d_cnt, sizeof(DevCounters), hipMemcpyDeviceToHost, s));
+	HIPCHK(c, hipStreamSynchronize(s));
 	c->n_halo = c->h_cnt->n_halo;
 	if (c->h_cnt->err_overflow)
 		FAIL(c, LS1HIP_ENOMEM, "device buffer overflow (%u records dropped): halo/export capacity exceeded", c->h_cnt->err_overflow);
@@ -671,15 +684,32 @@ extern "C" int ls1hip_halo(ls1hip_ctx* c) {
 	if (!c) return LS1HIP_EINVAL;
 	REQUIRE(c, c->binned, "ls1hip_rebin (and import_done(0) on multi-rank domains) must precede ls1hip_halo");
 	HIPCHK(c, hipSetDevice(c->device));
-	TimedScope ts(c, c->t_halo);
+	hipStream_t hs = halo_stream(c);
+	if (c->inner_in_flight) HIPCHK(c, hipStreamWaitEvent(hs, c->ev_owned, 0));  // the re-binned owned molecules
+	TimedScope ts(c, c->t_halo, hs);
 	HaloArgs a = halo_args(c);
-	launch_halo_generate(a, c->stream);
+	launch_halo_generate(a, hs);
 	if (!c->has_remote) {
-		launch_halo_finalize(a, c->stream);
+		launch_halo_finalize(a, hs);
 		c->halo_valid = true;
+		if (c->inner_in_flight) HIPCHK(c, hipEventRecord(c->ev_halo, hs));
 	}
 	HIPCHK(c, hipGetLastError());
 	c->forces_valid = false;
+	return LS1HIP_OK;
+}
+
+// Stream discipline of the force passes.  which = 1 (inner cells) marks the state the halo phase may read and leaves the
+// pass in flight: until the matching which = 2 call the halo phase (ls1hip_halo, export / import of kind 1) runs on the
+// second, high-priority stream, concurrently with the inner-cell kernel, and the host is never blocked by that kernel.
+// which = 2 (boundary cells) first waits for the populated halo.
+static int before_force_pass(ls1hip_ctx* c, int which) {
+	if (which == 1) {
+		HIPCHK(c, hipEventRecord(c->ev_owned, c->stream));
+	} else if (c->inner_in_flight) {
+		if (which == 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+		c->inner_in_flight = false;
+	}
 	return LS1HIP_OK;
 }
 
@@ -744,10 +774,12 @@ extern "C" int ls1hip_forces(ls1hip_ctx* c, int which, double* upot, double* vir
 	REQUIRE(c, !c->fused_split, "a fused inner pass (ls1hip_forces_kick_drift which=1) must be completed by its which=2 pass");
 	HIPCHK(c, hipSetDevice(c->device));
 	{
-		TimedScope ts(c, c->t_force);
-		int rc = launch_forces(c, which);
+		int rc = before_force_pass(c, which);
 		if (rc) return rc;
+		TimedScope ts(c, c->t_force);
+		if ((rc = launch_forces(c, which))) return rc;
 	}
+	if (which == 1) c->inner_in_flight = !c->halo_valid;  // halo already populated (old call order): nothing to overlap
 	if (which != 1) c->forces_valid = true;
 	if (upot || virial) {
 		int rc = sync_counters(c);
@@ -766,11 +798,13 @@ extern "C" int ls1hip_forces_kick_drift(ls1hip_ctx* c, int which, double dt, dou
 	REQUIRE(c, which == 2 ? c->fused_split == 1 : c->fused_split == 0, "fused passes must be which=0, or which=1 followed by which=2");
 	HIPCHK(c, hipSetDevice(c->device));
 	{
-		TimedScope ts(c, c->t_force);
-		int rc = launch_forces(c, which, true, dt);
+		int rc = before_force_pass(c, which);
 		if (rc) return rc;
+		TimedScope ts(c, c->t_force);
+		if ((rc = launch_forces(c, which, true, dt))) return rc;
 	}
 	if (which == 1) {
+		c->inner_in_flight = !c->halo_valid;
 		c->fused_split = 1;
 	} else {
 		// velocities are at t + dt/2 of the NEXT step and the advanced positions wait in the force arrays for ls1hip_rebin
@@ -1091,19 +1125,19 @@ extern "C" int ls1hip_export_counts(ls1hip_ctx* c, int kind, uint64_t counts[27]
 	if (!c || !counts) return LS1HIP_EINVAL;
 	REQUIRE(c, kind == 0 || kind == 1, "kind must be 0 or 1");
 	HIPCHK(c, hipSetDevice(c->device));
-	int rc = sync_counters(c);
+	int rc = sync_counters(c, kind == 1 ? halo_stream(c) : c->stream);
 	if (rc) return rc;
 	for (int d = 0; d < 27; ++d) counts[d] = kind == 0 ? c->h_cnt->exp_leave[d] : c->h_cnt->exp_halo[d];
 	return LS1HIP_OK;
 }
 
-static int export_pack_async(ls1hip_ctx* c, int kind, int dir, double* dst, size_t cap, uint32_t* n_out) {
+static int export_pack_async(ls1hip_ctx* c, int kind, int dir, double* dst, size_t cap, uint32_t* n_out, hipStream_t st) {
 	const uint32_t n = kind == 0 ? c->h_cnt->exp_leave[dir] : c->h_cnt->exp_halo[dir];
 	REQUIRE(c, cap >= n, "export buffer too small: %zu < %u records", cap, n);
 	const int w = kind == 0 ? LS1HIP_LEAVING_DOUBLES : LS1HIP_HALO_DOUBLES;
 	const double* src = kind == 0 ? c->d_exp_leave + (size_t)c->exp_off_leave[dir] * w
 								  : c->d_exp_halo + (size_t)c->exp_off_halo[dir] * w;
-	launch_pack_copy(dst, src, n * w, c->stream);
+	launch_pack_copy(dst, src, n * w, st);
 	*n_out = n;
 	return LS1HIP_OK;
 }
@@ -1113,9 +1147,10 @@ extern "C" int ls1hip_export_pack(ls1hip_ctx* c, int kind, int dir, void* dev_bu
 	REQUIRE(c, (kind == 0 || kind == 1) && dir >= 0 && dir < 27 && dev_buf, "bad argument");
 	HIPCHK(c, hipSetDevice(c->device));
 	uint32_t n = 0;
-	int rc = export_pack_async(c, kind, dir, (double*)dev_buf, cap, &n);
+	hipStream_t st = kind == 1 ? halo_stream(c) : c->stream;
+	int rc = export_pack_async(c, kind, dir, (double*)dev_buf, cap, &n, st);
 	if (rc) return rc;
-	HIPCHK(c, hipStreamSynchronize(c->stream));  // the transport runs on its own stream
+	HIPCHK(c, hipStreamSynchronize(st));  // the transport runs on its own stream
 	return LS1HIP_OK;
 }
 
@@ -1125,15 +1160,24 @@ extern "C" int ls1hip_export_pack_dirs(ls1hip_ctx* c, int kind, const int* dirs,
 			"bad argument");
 	HIPCHK(c, hipSetDevice(c->device));
 	const int w = kind == 0 ? LS1HIP_LEAVING_DOUBLES : LS1HIP_HALO_DOUBLES;
+	PackSegments seg;
+	seg.n = 0;
 	size_t used = 0;
 	for (int k = 0; k < ndirs; ++k) {
 		REQUIRE(c, dirs[k] >= 0 && dirs[k] < 27, "direction %d out of range", dirs[k]);
-		uint32_t n = 0;
-		int rc = export_pack_async(c, kind, dirs[k], (double*)dev_buf + used * w, cap - used, &n);
-		if (rc) return rc;
+		const uint32_t n = kind == 0 ? c->h_cnt->exp_leave[dirs[k]] : c->h_cnt->exp_halo[dirs[k]];
+		REQUIRE(c, cap - used >= n, "export buffer too small: %zu < %zu records", cap, used + n);
+		if (n == 0) continue;
+		seg.src_off[seg.n] = (uint64_t)(kind == 0 ? c->exp_off_leave[dirs[k]] : c->exp_off_halo[dirs[k]]) * w;
+		seg.dst_off[seg.n] = (uint64_t)used * w;
+		++seg.n;
 		used += n;
 	}
-	HIPCHK(c, hipStreamSynchronize(c->stream));  // one synchronisation per message: the transport runs on its own stream
+	seg.total = (uint64_t)used * w;
+	hipStream_t st = kind == 1 ? halo_stream(c) : c->stream;
+	launch_pack_segments(seg, kind == 0 ? c->d_exp_leave : c->d_exp_halo, (double*)dev_buf, st);
+	HIPCHK(c, hipGetLastError());
+	HIPCHK(c, hipStreamSynchronize(st));  // one synchronisation per message set: the transport runs on its own stream
 	return LS1HIP_OK;
 }
 
@@ -1149,7 +1193,7 @@ extern "C" int ls1hip_import(ls1hip_ctx* c, int kind, const void* dev_buf, size_
 		c->pending_in += (uint32_t)n;
 	} else {
 		HaloArgs a = halo_args(c);
-		launch_halo_import(a, (const double*)dev_buf, (uint32_t)n, c->stream);
+		launch_halo_import(a, (const double*)dev_buf, (uint32_t)n, halo_stream(c));
 	}
 	// asynchronous: dev_buf is read on the engine's stream and must stay valid until ls1hip_import_done(kind) returns
 	return LS1HIP_OK;
@@ -1169,9 +1213,14 @@ extern "C" int ls1hip_import_done(ls1hip_ctx* c, int kind) {
 	} else {
 		REQUIRE(c, c->binned, "halo import before rebin");
 		HaloArgs a = halo_args(c);
-		launch_halo_finalize(a, c->stream);
+		hipStream_t hs = halo_stream(c);
+		{
+			TimedScope ts(c, c->t_halo, hs);
+			launch_halo_finalize(a, hs);
+		}
 		c->halo_valid = true;
-		HIPCHK(c, hipStreamSynchronize(c->stream));  // imported buffers may be released by the caller from here on
+		if (c->inner_in_flight) HIPCHK(c, hipEventRecord(c->ev_halo, hs));
+		HIPCHK(c, hipStreamSynchronize(hs));  // imported buffers may be released by the caller from here on
 	}
 	return LS1HIP_OK;
 }

@@ -96,6 +96,12 @@ struct Timer {
 struct ls1hip_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
+	// second (high-priority) stream: while an inner-cell force pass (which = 1) is in flight on `stream`, the halo phase
+	// (generation, packing, import, sort) runs here; ev_owned marks the state the halo phase may read (recorded on
+	// `stream` just before the inner pass), ev_halo the populated halo the boundary pass (which = 2) waits for
+	hipStream_t stream2 = nullptr;
+	hipEvent_t ev_owned = nullptr, ev_halo = nullptr;
+	bool inner_in_flight = false;
 	std::string err;
 	// options
 	long opt_force_kernel = LS1HIP_FK_AUTO, opt_cic = 1, opt_vi = 0, opt_det = 1, opt_count_pairs = 0, opt_lj_split = 0;
@@ -193,6 +199,13 @@ void launch_halo_import(const HaloArgs& a, const double* dev_records, uint32_t n
 void launch_halo_finalize(const HaloArgs& a, hipStream_t s);
 void launch_leave_import(const RebinArgs& a, const double* dev_records, uint32_t n, uint32_t at, hipStream_t s);
 void launch_pack_copy(double* dst, const double* src, uint32_t ndoubles, hipStream_t s);
+// up to 27 (source offset -> destination offset) runs of doubles copied by one launch; dst_off is ascending
+struct PackSegments {
+	int n;
+	uint64_t total;
+	uint64_t src_off[27], dst_off[27];
+};
+void launch_pack_segments(const PackSegments& seg, const double* src, double* dst, hipStream_t s);
 
 void launch_force_generic(const ForceParams& p, bool one_clj, bool with_vi, bool has_rot, hipStream_t s, uint32_t* nblocks);
 // LDS-tiled 1CLJ kernel (kernels_force_lj.hip); returns false if it cannot handle the configuration

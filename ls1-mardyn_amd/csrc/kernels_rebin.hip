@@ -354,6 +354,19 @@ __global__ void __launch_bounds__(TPB) k_copy(double* dst, const double* src, ui
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	if (i < n) dst[i] = src[i];
 }
+// all segments of a message set in ONE launch (a launch per direction was 26 x 2.6 us per exchange)
+__global__ void __launch_bounds__(TPB) k_copy_segments(PackSegments seg, const double* src, double* dst) {
+	const uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+	if (i >= seg.total) return;
+	int k = 0;
+	while (k + 1 < seg.n && i >= seg.dst_off[k + 1]) ++k;  // scalar-ish walk over <= 27 prefix offsets
+	dst[i] = src[seg.src_off[k] + (i - seg.dst_off[k])];
+}
+void launch_pack_segments(const PackSegments& seg, const double* src, double* dst, hipStream_t s) {
+	if (seg.total == 0 || seg.n == 0) return;
+	hipLaunchKernelGGL(k_copy_segments, dim3((uint32_t)((seg.total + TPB - 1) / TPB)), dim3(TPB), 0, s, seg, src, dst);
+}
+
 void launch_pack_copy(double* dst, const double* src, uint32_t ndoubles, hipStream_t s) {
 	if (ndoubles == 0) return;
 	hipLaunchKernelGGL(k_copy, dim3((ndoubles + TPB - 1) / TPB), dim3(TPB), 0, s, dst, src, ndoubles);

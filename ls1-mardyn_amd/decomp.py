@@ -44,7 +44,11 @@ def dims_create(world: int):
 class CartesianDecomposition:
     """Geometry of the rank grid: coordinates, bounding boxes, the 27-entry neighbour table."""
 
-    def __init__(self, world: int, rank: int, global_len, grid=None, periodic=(True, True, True)):
+    def __init__(self, world: int, rank: int, global_len, grid=None, periodic=(True, True, True), loopback=False):
+        # loopback (rehearsal / diagnostics): periodic images that a rank would create locally (neighbour == itself) are
+        # routed through the transport instead, as messages to the alias id world + rank (sent to and received from the
+        # own rank).  Exercises the full export -> RCCL -> import path, on ONE GPU if need be.
+        self.loopback = bool(loopback)
         self.world, self.rank = int(world), int(rank)
         self.grid = tuple(grid) if grid is not None else dims_create(world)
         assert int(np.prod(self.grid)) == world
@@ -88,7 +92,16 @@ class CartesianDecomposition:
                             x %= self.grid[d]
                         n.append(x)
                     tab[(sz + 1) * 9 + (sy + 1) * 3 + (sx + 1)] = self.rank_of(n) if ok else -1
+        if self.loopback:
+            owner = self.rank if rank is None else int(rank)
+            alias = np.where(tab == owner, self.world + owner, tab)
+            alias[13] = owner
+            tab = alias.astype(np.int32)
         return tab
+
+    def real_rank(self, peer: int) -> int:
+        """process that serves peer id `peer` (loopback aliases map to their owner)"""
+        return int(peer) - self.world if int(peer) >= self.world else int(peer)
 
     def peers(self):
         me = self.rank
@@ -111,10 +124,33 @@ class HaloExchanger:
         # directions of every rank that point at me, per source rank (to size the receive)
         self._incoming = {}
         for p in self.peers:
-            t = decomp.neighbor_table(p)
-            self._incoming[p] = [d for d in range(27) if d != 13 and t[d] == decomp.rank]
+            t = decomp.neighbor_table(decomp.real_rank(p))
+            # a message from peer p carries the directions of p's table that point at me (at my alias for a loopback)
+            me = p if decomp.real_rank(p) == decomp.rank else decomp.rank
+            self._incoming[p] = [d for d in range(27) if d != 13 and t[d] == me]
         self._outgoing = {p: [d for d in range(27) if d != 13 and self.nbr[d] == p] for p in self.peers}
         self._torch = __import__("torch")
+        # The 27 record counts per rank travel over a host-side (gloo) group: a device-side all_gather would put its
+        # small copies on the HIP null stream, whose hardware queue is shared with the engine's main stream — they
+        # would queue behind the 2.4 ms inner-cell kernel and serialise the halo exchange with it (rocprof trace).
+        self._comm_stream = None
+        self.meta_group = None
+        if not self.stage and decomp.world > 1:
+            try:
+                self.meta_group = dist.new_group(backend="gloo")
+            except Exception:  # no gloo transport: fall back to the device all_gather (correct, less overlap)
+                self.meta_group = None
+
+    def _gather_counts(self, counts):
+        """[world, 27] int64 table of every rank's export counts"""
+        torch, dist = self._torch, self.dist
+        if self.dc.world == 1:
+            return counts[None, :]
+        host = self.stage or self.meta_group is not None
+        mine = torch.from_numpy(counts).to("cpu" if host else self.device)
+        lst = [torch.empty_like(mine) for _ in range(self.dc.world)]
+        dist.all_gather(lst, mine, group=self.group if self.meta_group is None else self.meta_group)
+        return torch.stack(lst).cpu().numpy()
 
     def _ptr(self, t):
         return t.data_ptr()
@@ -126,14 +162,11 @@ class HaloExchanger:
         w = RECORD_DOUBLES[kind]
         counts = self.engine.export_counts(kind).astype(np.int64)  # [27]
         if self.peers:
-            mine = torch.from_numpy(counts).to("cpu" if self.stage else self.device)
-            lst = [torch.empty_like(mine) for _ in range(self.dc.world)]
-            dist.all_gather(lst, mine, group=self.group)
-            allc = torch.stack(lst).cpu().numpy()
+            allc = self._gather_counts(counts)
         # ONE device buffer holds every outgoing message (directions grouped by peer) and ONE every incoming message:
         # one pack call / one import call / one stream synchronisation per exchange, whatever the number of peers
         n_out = {p: int(sum(counts[d] for d in self._outgoing[p])) for p in self.peers}
-        n_in = {p: int(sum(allc[p][d] for d in self._incoming[p])) for p in self.peers}
+        n_in = {p: int(sum(allc[self.dc.real_rank(p)][d] for d in self._incoming[p])) for p in self.peers}
         tot_out, tot_in = sum(n_out.values()), sum(n_in.values())
         ops = []
         sbuf = rbuf = None
@@ -147,22 +180,34 @@ class HaloExchanger:
             off = 0
             for p in self.peers:
                 if n_out[p]:
-                    ops.append(dist.P2POp(dist.isend, sbuf[off * w:(off + n_out[p]) * w], p, group=self.group))
+                    ops.append(dist.P2POp(dist.isend, sbuf[off * w:(off + n_out[p]) * w], self.dc.real_rank(p), group=self.group))
                     off += n_out[p]
         if tot_in:
             rbuf = torch.empty(tot_in * w, dtype=torch.float64, device="cpu" if self.stage else self.device)
             off = 0
             for p in self.peers:
                 if n_in[p]:
-                    ops.append(dist.P2POp(dist.irecv, rbuf[off * w:(off + n_in[p]) * w], p, group=self.group))
+                    ops.append(dist.P2POp(dist.irecv, rbuf[off * w:(off + n_in[p]) * w], self.dc.real_rank(p), group=self.group))
                     off += n_in[p]
-        reqs = dist.batch_isend_irecv(ops) if ops else []
-        if overlap_fn is not None:
-            overlap_fn()
-        for r in reqs:
-            r.wait()
+        # The transfers are issued from a dedicated side stream: RCCL orders its kernels after an event on the CURRENT
+        # torch stream, and the default (null) stream shares its hardware queue with the engine's main stream — the
+        # event, and with it the whole transfer, would wait for the inner-cell kernel (seen in the rocprof trace).
         if self.device.type == "cuda":
-            torch.cuda.current_stream().synchronize()
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=self.device, priority=-1)
+            with torch.cuda.stream(self._comm_stream):
+                reqs = dist.batch_isend_irecv(ops) if ops else []
+                if overlap_fn is not None:
+                    overlap_fn()
+                for r in reqs:
+                    r.wait()
+                self._comm_stream.synchronize()
+        else:
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+            if overlap_fn is not None:
+                overlap_fn()
+            for r in reqs:
+                r.wait()
         if tot_in:
             if self.stage:
                 rbuf = rbuf.to(self.device)
@@ -187,22 +232,29 @@ class DistributedSimulation:
         e = self.engine
         e.rebin()
         self.ex.exchange(LEAVING)
+        e.forces(1, want_macro=False)
         e.halo()
-        self.ex.exchange(HALO, overlap_fn=lambda: e.forces(1, want_macro=False))
+        self.ex.exchange(HALO)
         return e.forces(2)
 
     def _exchange_and_forces(self, want, fuse_dt=None):
-        """re-bin + migration, halo exchange overlapped with the inner-cell traversal, boundary traversal.  With
-        fuse_dt the force passes also integrate (ls1hip_forces_kick_drift): no F round trip, no integrator pass."""
+        """re-bin + migration, then the inner-cell traversal is launched FIRST (it needs the owned molecules only) and
+        the whole halo phase — image generation, count exchange, packing, RCCL transfer, import, sort — runs while
+        it computes: the engine moves the halo phase to its second (high-priority) stream as long as an inner pass
+        is in flight, and none of the host synchronisations of the exchange waits for the inner kernel.  The boundary
+        traversal waits (on the device) for the populated halo.  With fuse_dt the force passes also integrate
+        (ls1hip_forces_kick_drift): no F round trip, no integrator pass."""
         e = self.engine
         e.rebin()
         self.ex.exchange(LEAVING)
-        e.halo()
-        # halo records travel while the compute stream traverses the inner cells
         if fuse_dt is None:
-            self.ex.exchange(HALO, overlap_fn=lambda: e.forces(1, want_macro=False))
+            e.forces(1, want_macro=False)
+        else:
+            e.forces_kick_drift(1, fuse_dt)
+        e.halo()
+        self.ex.exchange(HALO)
+        if fuse_dt is None:
             return e.forces(2, want_macro=want)
-        self.ex.exchange(HALO, overlap_fn=lambda: e.forces_kick_drift(1, fuse_dt))
         return e.forces_kick_drift(2, fuse_dt, want_macro=want)
 
     def step(self, dt, want=False):
@@ -248,7 +300,7 @@ class DistributedSimulation:
 
 
 def build_weak_scaling_box(comps, rc, n_per_dim, world, rank, local_rank, bcc_box, cic=None, kernel=0,
-                           stage_through_host=False):
+                           stage_through_host=False, loopback=False):
     """bench.py helper: every rank owns a 2*n^3 jittered bcc block; the global box is the rank grid of such blocks."""
     import torch
     import torch.distributed as dist
@@ -258,7 +310,7 @@ def build_weak_scaling_box(comps, rc, n_per_dim, world, rank, local_rank, bcc_bo
     grid = dims_create(world)
     Ls, r, v = bcc_box(n_per_dim, seed=1234 + rank)
     global_len = np.array([Ls * g for g in grid])
-    dc = CartesianDecomposition(world, rank, global_len, grid)
+    dc = CartesianDecomposition(world, rank, global_len, grid, loopback=loopback)
     lo, hi = dc.bounding_box()
     r = r + lo
     for d in range(3):  # numerical safety: stay strictly inside the own sub-box

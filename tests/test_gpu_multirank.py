@@ -180,3 +180,50 @@ def test_fused_integration_across_subboxes(world):
     assert np.max(np.abs(dr)) < 1e-11
     assert np.max(np.abs(a["v"] - b["v"])) < 1e-11 * np.max(np.abs(a["v"]))
     assert np.max(np.abs(a["F"] - b["F"])) < 1e-10 * np.max(np.abs(a["F"]))
+
+
+def test_loopback_transport_equals_local_images():
+    """The distributed step loop on ONE rank with its periodic images routed through the real transport (RCCL
+    send/recv to the own rank, all 26 directions exported, packed, transferred, imported on the second stream while the
+    inner-cell pass runs) == the same loop with local images == the in-engine loop: positions, velocities bitwise,
+    U_pot to rounding.  Covers the stream discipline of the overlapped exchange on a single GPU."""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        L, r, v = _liquid(24)  # 27 648 atoms, 12 cells per dimension
+        rc, dt, nsteps = 2.5, 0.004, 6
+        ids = np.arange(1, len(r) + 1, dtype=np.uint64)
+        comps = inp.ComponentSet([inp.make_component(lj=[(0, 0, 0, 1, 1, 1, rc, 0)])], np.zeros((0, 2)), 1e10)
+        out = {}
+        for mode in ("engine", "local", "loopback"):
+            e = engine_mod.DeviceEngine(0)
+            e.set_components(comps, rc)
+            if mode == "engine":
+                e.set_domain(L)
+                e.upload(ids, np.zeros(len(ids), np.int32), r, v)
+                e.rebin(); e.halo(); e.forces(0)
+                res = e.run(dt, nsteps)
+            else:
+                dc = decomp.CartesianDecomposition(1, 0, L, loopback=(mode == "loopback"))
+                lo, hi = dc.bounding_box()
+                e.set_domain(L, lo, hi, 0, dc.neighbor_table())
+                e.upload(ids, np.zeros(len(ids), np.int32), r, v)
+                sim = decomp.DistributedSimulation(dc, e, dist, torch.device("cuda", 0))
+                sim.n_global = len(ids)
+                sim.initial_forces()
+                res = sim.run(dt, nsteps)
+            st = e.download_state()
+            o = np.argsort(st["ids"])
+            out[mode] = (st["r"][o], st["v"][o], res["upot"], res["summv2"])
+            e.close()
+        for mode in ("local", "loopback"):
+            assert np.array_equal(out["engine"][0], out[mode][0]), mode
+            assert np.array_equal(out["engine"][1], out[mode][1]), mode
+            assert abs(out["engine"][2] - out[mode][2]) <= 1e-12 * abs(out["engine"][2]), mode
+            assert abs(out["engine"][3] - out[mode][3]) <= 1e-12 * abs(out["engine"][3]), mode
+    finally:
+        dist.destroy_process_group()

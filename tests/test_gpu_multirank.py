@@ -16,7 +16,7 @@ inp = load_pkg("inp")
 
 
 class InProcessCluster:
-    def __init__(self, world, comps, rc, L, ids, r, v, grid=None, kernel=0):
+    def __init__(self, world, comps, rc, L, ids, r, v, grid=None, kernel=0, cid=None, q=None, D=None):
         import torch
         self.torch = torch
         self.world = world
@@ -29,7 +29,8 @@ class InProcessCluster:
             e.set_option("force_kernel", kernel)
             e.set_domain(L, lo, hi, dc.rank, dc.neighbor_table())
             m = np.all((r >= lo) & (r < hi), axis=1)
-            e.upload(ids[m], np.zeros(m.sum(), np.int32), r[m], v[m])
+            e.upload(ids[m], np.zeros(m.sum(), np.int32) if cid is None else cid[m], r[m], v[m],
+                     None if q is None else q[m], None if D is None else D[m])
             self.eng.append(e)
 
     def exchange(self, kind):
@@ -105,7 +106,8 @@ class InProcessCluster:
         ids = np.concatenate([s["ids"] for s in st])
         o = np.argsort(ids)
         return dict(ids=ids[o], r=np.concatenate([s["r"] for s in st])[o], v=np.concatenate([s["v"] for s in st])[o],
-                    F=np.concatenate([f["F"] for f in fr])[o])
+                    q=np.concatenate([s["q"] for s in st])[o], D=np.concatenate([s["D"] for s in st])[o],
+                    F=np.concatenate([f["F"] for f in fr])[o], M=np.concatenate([f["M"] for f in fr])[o])
 
 
 def _liquid(n, seed=11, rho=0.785302672):
@@ -227,3 +229,56 @@ def test_loopback_transport_equals_local_images():
             assert abs(out["engine"][3] - out[mode][3]) <= 1e-12 * abs(out["engine"][3]), mode
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_multisite_subboxes_equal_single_domain(world):
+    """BASELINE configs[4] flavour on a decomposed domain: the five-component LJ + charge + dipole + quadrupole set
+    (orientations and angular momenta travel in the leaving records, orientations in the halo records): sub-boxes ==
+    single domain for forces, torques and a short rotational trajectory with migration."""
+    from golden_io import input_path
+    ps0 = inp.read_inp(input_path("VectorizationMultiComponentMultiPotentials.inp"))
+    comps = ps0.components
+    rng = np.random.default_rng(17)
+    n = 10
+    N = 2 * n ** 3
+    rho = 250.0 / 134.266123 ** 3
+    Lx = (N / rho) ** (1.0 / 3.0)
+    a = Lx / n
+    g = np.stack(np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij"), -1).reshape(-1, 3) * a
+    r = (np.concatenate([g + 0.25 * a, g + 0.75 * a]) + 0.2 * a * rng.uniform(-0.5, 0.5, (N, 3))) % Lx
+    q = rng.normal(size=(N, 4)); q /= np.linalg.norm(q, axis=1)[:, None]
+    cid = (np.arange(N) % 5).astype(np.int32)
+    v = rng.normal(0, 1.0, (N, 3))  # fast enough that some molecules cross sub-box faces within a few steps
+    D = rng.normal(0, 1e-3, (N, 3))
+    L = np.array([Lx] * 3)
+    rc, dt, nsteps = 35.0, 0.5, 4
+    ids = np.arange(1, N + 1, dtype=np.uint64)
+    single = InProcessCluster(1, comps, rc, L, ids, r, v, cid=cid, q=q, D=D)
+    multi = InProcessCluster(world, comps, rc, L, ids, r, v, cid=cid, q=q, D=D)
+    t1 = single.forces(split=False)
+    tm = multi.forces()
+    a1, b1 = single.gather(), multi.gather()
+    assert np.array_equal(a1["ids"], b1["ids"])
+    for k in ("F", "M"):
+        assert np.max(np.abs(a1[k] - b1[k])) < 1e-11 * np.max(np.abs(a1[k])), k
+    assert np.allclose(t1, tm, rtol=1e-11)
+    # trajectory: components 0 and 1 of the fixture are massless multipoles (static force tests only), so the moving
+    # system uses components 2..4 (LJ / charge / dipole / quadrupole sites with mass and moments of inertia)
+    cid = (2 + np.arange(N) % 3).astype(np.int32)
+    single = InProcessCluster(1, comps, rc, L, ids, r, v, cid=cid, q=q, D=D)
+    multi = InProcessCluster(world, comps, rc, L, ids, r, v, cid=cid, q=q, D=D)
+    single.forces(split=False)
+    multi.forces()
+    for _ in range(nsteps):
+        single.step(dt)
+        multi.step(dt)
+    a1, b1 = single.gather(), multi.gather()
+    assert np.array_equal(a1["ids"], b1["ids"])
+    moved = np.max(np.abs(a1["r"] - r))
+    assert moved > 1.0  # the molecules really travelled
+    dr = a1["r"] - b1["r"]
+    dr -= L * np.round(dr / L)
+    assert np.max(np.abs(dr)) < 1e-9
+    for k in ("v", "q", "D"):
+        assert np.max(np.abs(a1[k] - b1[k])) < 1e-9 * max(np.max(np.abs(a1[k])), 1e-300), k

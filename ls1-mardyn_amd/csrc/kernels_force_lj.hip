@@ -148,48 +148,15 @@ __global__ void __launch_bounds__(LTPB * SPLIT, 2 * SPLIT) k_force_lj_brick(Forc
 	__shared__ double red[NT / 64][2];
 
 	const int tid = threadIdx.x;
-	// XCD-aware brick order: workgroups are dealt round-robin to the 8 XCDs, so give every XCD a contiguous run of
-	// bricks (neighbouring bricks share most of their shell -> they hit the same 4 MB L2).
-	// With a brick list (inner / boundary traversal) only the listed bricks are launched: an empty 512-thread, 80 KB
-	// workgroup still costs ~20 ns of dispatch, which made the boundary pass (18 % of the bricks) 2x too slow.
-	const int nb = P.brick_list ? (int)P.n_list : nbx * nby * nbz;
-	const int chunk = gridDim.x / 8;  // the grid is 8 * ceil(nb / 8) workgroups
-	const int slot = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
-	bool live = slot < nb;
-	const int brick = (live && P.brick_list) ? (int)P.brick_list[slot] : slot;
-	int bx = 0, by = 0, bz = 0;
-	if (live) {
-		bx = brick % nbx;
-		by = (brick / nbx) % nby;
-		bz = brick / (nbx * nby);
-	}
-	// brick origin in grid cell coordinates and its extent (edge bricks are partial)
-	const int x0 = HW + bx * BX, y0 = HW + by * BY, z0 = HW + bz * BZ;
-	const int ex = min(BX, P.g.dims[0] - HW - x0), ey = min(BY, P.g.dims[1] - HW - y0), ez = min(BZ, P.g.dims[2] - HW - z0);
-	if (live && P.which != 0 && !P.brick_list) {
-		// "inner" brick: no halo cell inside its shell (cells [2hw, dims-2hw) in every dimension)
-		const bool inner = x0 >= 2 * HW && y0 >= 2 * HW && z0 >= 2 * HW && x0 + ex <= P.g.dims[0] - 2 * HW &&
-						   y0 + ey <= P.g.dims[1] - 2 * HW && z0 + ez <= P.g.dims[2] - 2 * HW;
-		live = (P.which == 1) ? inner : !inner;
-	}
-	if (!live) {  // uniform per block
+	const BrickSel bs = brick_select<HW, BX, BY, BZ>(P, nbx, nby, nbz);
+	if (!bs.live) {  // uniform per workgroup
 		if (tid < 4) P.partials[(size_t)blockIdx.x * 4 + tid] = 0.;
 		return;
 	}
+	const int ex = bs.ex, ey = bs.ey, ez = bs.ez;
 
 	// ---- 1. region cell table ------------------------------------------------------------------------------------
-	for (int c = tid; c < NRC; c += NT) {
-		const int rx = c % RX, ry = (c / RX) % RY, rz = c / (RX * RY);
-		const int gx = x0 - HW + rx, gy = y0 - HW + ry, gz = z0 - HW + rz;
-		uint32_t b = 0, n = 0;
-		if (gx < P.g.dims[0] && gy < P.g.dims[1] && gz < P.g.dims[2]) {  // lower bounds are >= 0 by construction
-			const int gc = cell_index(P.g, gx, gy, gz);
-			b = P.cell_begin[gc];
-			n = P.cell_end[gc] - b;
-		}
-		gbeg[c] = b;
-		cstart[c] = n;
-	}
+	brick_region_table<NT, HW, RX, RY, RZ>(P, bs, cstart, gbeg);
 	__syncthreads();
 	block_scan_lds<NT>(cstart, NRC, wsum);
 	const uint32_t total = cstart[NRC];
@@ -447,41 +414,14 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 	__shared__ double red[NW][2];
 
 	const int tid = threadIdx.x;
-	const int nb = P.brick_list ? (int)P.n_list : nbx * nby * nbz;
-	const int chunk = gridDim.x / 8;
-	const int slot = (blockIdx.x % 8) * chunk + blockIdx.x / 8;  // XCD-aware brick order (see k_force_lj_brick)
-	bool live = slot < nb;
-	const int brick = (live && P.brick_list) ? (int)P.brick_list[slot] : slot;
-	int bx = 0, by = 0, bz = 0;
-	if (live) {
-		bx = brick % nbx;
-		by = (brick / nbx) % nby;
-		bz = brick / (nbx * nby);
-	}
-	const int x0 = HW + bx * BX, y0 = HW + by * BY, z0 = HW + bz * BZ;
-	const int ex = min(BX, P.g.dims[0] - HW - x0), ey = min(BY, P.g.dims[1] - HW - y0), ez = min(BZ, P.g.dims[2] - HW - z0);
-	if (live && P.which != 0 && !P.brick_list) {
-		const bool inner = x0 >= 2 * HW && y0 >= 2 * HW && z0 >= 2 * HW && x0 + ex <= P.g.dims[0] - 2 * HW &&
-						   y0 + ey <= P.g.dims[1] - 2 * HW && z0 + ez <= P.g.dims[2] - 2 * HW;
-		live = (P.which == 1) ? inner : !inner;
-	}
-	if (!live) {
+	const BrickSel bs = brick_select<HW, BX, BY, BZ>(P, nbx, nby, nbz);
+	if (!bs.live) {  // uniform per workgroup
 		if (tid < 4) P.partials[(size_t)blockIdx.x * 4 + tid] = 0.;
 		return;
 	}
+	const int x0 = bs.x0, y0 = bs.y0, z0 = bs.z0, ex = bs.ex, ey = bs.ey, ez = bs.ez;
 	// ---- region cell table + staging (as in k_force_lj_brick) ---------------------------------------------------------
-	for (int c = tid; c < NRC; c += NT) {
-		const int rx = c % RX, ry = (c / RX) % RY, rz = c / (RX * RY);
-		const int gx = x0 - HW + rx, gy = y0 - HW + ry, gz = z0 - HW + rz;
-		uint32_t b = 0, n = 0;
-		if (gx < P.g.dims[0] && gy < P.g.dims[1] && gz < P.g.dims[2]) {
-			const int gc = cell_index(P.g, gx, gy, gz);
-			b = P.cell_begin[gc];
-			n = P.cell_end[gc] - b;
-		}
-		gbeg[c] = b;
-		cstart[c] = n;
-	}
+	brick_region_table<NT, HW, RX, RY, RZ>(P, bs, cstart, gbeg);
 	__syncthreads();
 	block_scan_lds<NT>(cstart, NRC, wsum);
 	const uint32_t total = cstart[NRC];

@@ -58,41 +58,14 @@ __global__ void __launch_bounds__(MTPB) k_force_ms_brick(ForceParams P, int nbx,
 	__shared__ double red[NT / 64][4];
 
 	const int tid = threadIdx.x;
-	const int nb = P.brick_list ? (int)P.n_list : nbx * nby * nbz;
-	const int chunk = gridDim.x / 8;
-	const int slot = (blockIdx.x % 8) * chunk + blockIdx.x / 8;  // XCD-aware brick order (see k_force_lj_brick)
-	bool live = slot < nb;
-	const int brick = (live && P.brick_list) ? (int)P.brick_list[slot] : slot;
-	int bx = 0, by = 0, bz = 0;
-	if (live) {
-		bx = brick % nbx;
-		by = (brick / nbx) % nby;
-		bz = brick / (nbx * nby);
-	}
-	const int x0 = HW + bx * BX, y0 = HW + by * BY, z0 = HW + bz * BZ;
-	const int ex = min(BX, P.g.dims[0] - HW - x0), ey = min(BY, P.g.dims[1] - HW - y0), ez = min(BZ, P.g.dims[2] - HW - z0);
-	if (live && P.which != 0 && !P.brick_list) {
-		const bool inner = x0 >= 2 * HW && y0 >= 2 * HW && z0 >= 2 * HW && x0 + ex <= P.g.dims[0] - 2 * HW &&
-						   y0 + ey <= P.g.dims[1] - 2 * HW && z0 + ez <= P.g.dims[2] - 2 * HW;
-		live = (P.which == 1) ? inner : !inner;
-	}
-	if (!live) {
+	const BrickSel bs = brick_select<HW, BX, BY, BZ>(P, nbx, nby, nbz);
+	if (!bs.live) {  // uniform per workgroup
 		if (tid < 4) P.partials[(size_t)blockIdx.x * 4 + tid] = 0.;
 		return;
 	}
+	const int ex = bs.ex, ey = bs.ey, ez = bs.ez;
 	// ---- region cell table, brick cell prefix --------------------------------------------------------------------------
-	for (int c = tid; c < NRC; c += NT) {
-		const int rx = c % RX, ry = (c / RX) % RY, rz = c / (RX * RY);
-		const int gx = x0 - HW + rx, gy = y0 - HW + ry, gz = z0 - HW + rz;
-		uint32_t b = 0, n = 0;
-		if (gx < P.g.dims[0] && gy < P.g.dims[1] && gz < P.g.dims[2]) {
-			const int gc = cell_index(P.g, gx, gy, gz);
-			b = P.cell_begin[gc];
-			n = P.cell_end[gc] - b;
-		}
-		gbeg[c] = b;
-		cstart[c] = n;
-	}
+	brick_region_table<NT, HW, RX, RY, RZ>(P, bs, cstart, gbeg);
 	__syncthreads();
 	block_scan_lds<NT>(cstart, NRC, wsum);
 	const uint32_t total = cstart[NRC];

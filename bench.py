@@ -182,6 +182,8 @@ def main():
         sim = decomp.build_weak_scaling_box(comps, RC, n, world, rank, local_rank, bcc_box, cic=args.cic or None,
                                             kernel=args.kernel, stage_through_host=rehearse, loopback=args.loopback)
         n_total = sim.n_global
+        if args.loopback:  # rehearse the count exchange too (skipped otherwise when there is a single rank)
+            sim.ex.force_count_exchange = True
     else:
         engine_mod = importlib.import_module("ls1-mardyn_amd.engine")
         L, r, v = bcc_box(n)

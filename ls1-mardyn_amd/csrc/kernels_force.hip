@@ -91,7 +91,8 @@ __device__ __forceinline__ void generic_pair(const ForceParams& P, int ci, const
 // body — up to 16 x 16 site interactions with on-the-fly rotations — then runs over the list with every lane busy.
 // Evaluating the body inside the search loop made the whole wave execute it whenever ANY lane had a hit, i.e. almost
 // every iteration at ~15 % useful lanes (measured: ethane 9.8 M molecules 18.5 ms -> see DESIGN.md).  The list keeps the
-// candidate order, so the sums are bitwise those of the single loop.  A lane whose list overflows re-scans directly.
+// candidate order, so the sums are bitwise those of the single loop.  Neighbourhoods with more hits than the list holds
+// are processed in several windows of the same two phases.
 constexpr int GCAP = 79;  // list entries per lane: (GCAP + 1) x 128 x 4 B = 40 KB -> 4 workgroups (8 waves) / CU, the VGPR limit of the multi-site body
 template <bool ONE_CLJ, bool WITH_VI, bool HAS_ROT>
 __global__ void __launch_bounds__(FTPB) k_force_generic(ForceParams P) {
@@ -135,33 +136,7 @@ __global__ void __launch_bounds__(FTPB) k_force_generic(ForceParams P) {
 		const double rc2 = ONE_CLJ ? P.rc2 : P.ct->rc2;
 		const double rclj2 = ONE_CLJ ? P.rc2 : P.ct->rclj2;
 		const int hw = P.g.hw;
-		// ---- phase 1: candidate search ---------------------------------------------------------------------------------
-		uint32_t cnt = 0;
-		uint32_t* const mylist = glist + threadIdx.x;
-		for (int dz = -hw; dz <= hw && !ONE_CLJ; ++dz)
-			for (int dy = -hw; dy <= hw; ++dy)
-				for (int dx = -hw; dx <= hw; ++dx) {
-					const int c2 = cell_index(P.g, cx + dx, cy + dy, cz + dz);
-					const uint32_t jb = P.cell_begin[c2], je = P.cell_end[c2];
-					for (uint32_t j = jb; j < je; ++j) {
-						const double ex = ri.x - P.x[j], ey = ri.y - P.y[j], ez = ri.z - P.z[j];
-						const double dd = ex * ex + ey * ey + ez * ez;
-						const bool hit = (dd < rc2) & (dd != 0.) & (j != p);
-						mylist[(hit ? min(cnt, (uint32_t)GCAP) : (uint32_t)GCAP) * FTPB] = j;
-						cnt += hit ? 1u : 0u;
-						++nchk;
-					}
-				}
-		nhit = cnt;
-		// ---- phase 2: molecule-pair bodies over the list ---------------------------------------------------------------
-		if (!ONE_CLJ && cnt <= (uint32_t)GCAP) {
-			for (uint32_t s = 0; s < cnt; ++s) {
-				const uint32_t j = mylist[s * FTPB];
-				const V3 rj = {P.x[j], P.y[j], P.z[j]};
-				const V3 drm = ri - rj;
-				generic_pair<ONE_CLJ, WITH_VI, HAS_ROT>(P, ci, ri, Ri, j, rj, drm, dot(drm, drm), rclj2, acc);
-			}
-		} else {
+		if (ONE_CLJ) {
 			for (int dz = -hw; dz <= hw; ++dz)
 				for (int dy = -hw; dy <= hw; ++dy)
 					for (int dx = -hw; dx <= hw; ++dx) {
@@ -172,12 +147,47 @@ __global__ void __launch_bounds__(FTPB) k_force_generic(ForceParams P) {
 							const V3 rj = {P.x[j], P.y[j], P.z[j]};
 							const V3 drm = ri - rj;
 							const double dd = dot(drm, drm);
-							if (ONE_CLJ) ++nchk;
+							++nchk;
 							if (!(dd < rc2) || dd == 0.) continue;
-							if (ONE_CLJ) ++nhit;
+							++nhit;
 							generic_pair<ONE_CLJ, WITH_VI, HAS_ROT>(P, ci, ri, Ri, j, rj, drm, dd, rclj2, acc);
 						}
 					}
+		} else {
+			// Windows of GCAP hits (one window unless the neighbourhood is very dense): phase 1 appends the hits number
+			// [done, done + GCAP) to the per-lane list, phase 2 runs the molecule-pair body over it.  ONE instantiation of
+			// the (large) body: a second inlined copy for an overflow path costs more in instruction-cache misses than
+			// the windowing does.  Candidate order is kept.
+			uint32_t* const mylist = glist + threadIdx.x;
+			uint32_t done = 0, seen;
+			do {
+				seen = 0;
+				uint32_t cnt = 0;
+				for (int dz = -hw; dz <= hw; ++dz)
+					for (int dy = -hw; dy <= hw; ++dy)
+						for (int dx = -hw; dx <= hw; ++dx) {
+							const int c2 = cell_index(P.g, cx + dx, cy + dy, cz + dz);
+							const uint32_t jb = P.cell_begin[c2], je = P.cell_end[c2];
+							for (uint32_t j = jb; j < je; ++j) {
+								const double ex = ri.x - P.x[j], ey = ri.y - P.y[j], ez = ri.z - P.z[j];
+								const double dd = ex * ex + ey * ey + ez * ez;
+								const bool hit = (dd < rc2) & (dd != 0.) & (j != p);
+								const bool take = hit & (seen >= done) & (seen < done + (uint32_t)GCAP);
+								mylist[(take ? seen - done : (uint32_t)GCAP) * FTPB] = j;
+								cnt += take ? 1u : 0u;
+								seen += hit ? 1u : 0u;
+								nchk += (done == 0) ? 1u : 0u;
+							}
+						}
+				for (uint32_t s = 0; s < cnt; ++s) {
+					const uint32_t j = mylist[s * FTPB];
+					const V3 rj = {P.x[j], P.y[j], P.z[j]};
+					const V3 drm = ri - rj;
+					generic_pair<ONE_CLJ, WITH_VI, HAS_ROT>(P, ci, ri, Ri, j, rj, drm, dot(drm, drm), rclj2, acc);
+				}
+				done += cnt;
+			} while (seen > done);
+			nhit = seen;
 		}
 		P.Fx[p] = acc.F.x;
 		P.Fy[p] = acc.F.y;

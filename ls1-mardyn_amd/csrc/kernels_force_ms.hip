@@ -56,6 +56,9 @@ __global__ void __launch_bounds__(MTPB) k_force_ms_brick(ForceParams P, int nbx,
 	__shared__ uint32_t bstart[NBC + 1];
 	__shared__ uint32_t wsum[NT / 64];
 	__shared__ double red[NT / 64][4];
+	constexpr int OWNCAP = 2 * NT;                  // bricks up to 512 owned molecules get the component-ordered lane map
+	__shared__ uint16_t oord[OWNCAP];               // lane slot -> owned enumeration index, grouped by component
+	__shared__ uint32_t ccnt[2][NT / 64][MAXC];     // per (round, wave, component) counts, then exclusive bases
 
 	const int tid = threadIdx.x;
 	const BrickSel bs = brick_select<HW, BX, BY, BZ>(P, nbx, nby, nbz);
@@ -109,11 +112,67 @@ __global__ void __launch_bounds__(MTPB) k_force_ms_brick(ForceParams P, int nbx,
 	__syncthreads();
 
 	const double rc2 = P.ct->rc2, rclj2 = P.ct->rclj2;
+	const int ncomp = P.ct->ncomp;
+	// owned enumeration index -> (region cell, rank in cell)
+	auto locate = [&](uint32_t it, int& lo_out) {
+		int lo = 0, hi = NBC;
+		while (hi - lo > 1) {
+			const int mid = (lo + hi) >> 1;
+			if (bstart[mid] <= it) lo = mid;
+			else hi = mid;
+		}
+		lo_out = lo;
+	};
+	// ---- component-ordered lane map -------------------------------------------------------------------------------------
+	// With several components the molecule-pair body branches on (ci, cj); lanes of a wave that hold different components
+	// walk every branch.  The owned molecules of the brick are therefore handed to the lanes grouped by component
+	// (deterministic: stable counting sort by wave ballots), so that ci is (nearly) wave-uniform in phase 2.  Bucketing each
+	// lane's candidates by THEIR component as well was tried: the per-bucket wave-max trip counts (42 vs 29 trips) ate the
+	// gain.  Upper bound with both uniform (components in slabs): 24.1 -> 11.6 ms for the 10^7-molecule five-component set.
+	const bool by_comp = staged && ncomp > 1 && n_i <= (uint32_t)OWNCAP;
+	if (by_comp) {
+		const int lane = tid & 63, wv = tid >> 6;
+		int myc[2];
+		for (int r = 0; r < 2; ++r) {
+			const uint32_t it = (uint32_t)(r * NT + tid);
+			int c = -1;
+			if (it < n_i) {
+				int lo;
+				locate(it, lo);
+				const int cx = lo % BX, cy = (lo / BX) % BY, cz = lo / (BX * BY);
+				c = scid[cstart[((cz + HW) * RY + (cy + HW)) * RX + (cx + HW)] + (it - bstart[lo])];
+			}
+			myc[r] = c;
+			for (int c8 = 0; c8 < ncomp; ++c8) {
+				const unsigned long long m = __ballot(c == c8);
+				if (lane == 0) ccnt[r][wv][c8] = (uint32_t)__popcll(m);
+			}
+		}
+		__syncthreads();
+		if (tid == 0) {
+			uint32_t run = 0;
+			for (int c8 = 0; c8 < ncomp; ++c8)
+				for (int r = 0; r < 2; ++r)
+					for (int w = 0; w < NT / 64; ++w) {
+						const uint32_t t = ccnt[r][w][c8];
+						ccnt[r][w][c8] = run;
+						run += t;
+					}
+		}
+		__syncthreads();
+		for (int r = 0; r < 2; ++r)
+			for (int c8 = 0; c8 < ncomp; ++c8) {
+				const unsigned long long m = __ballot(myc[r] == c8);
+				if (myc[r] == c8) oord[ccnt[r][wv][c8] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(r * NT + tid);
+			}
+		__syncthreads();
+	}
 	double u6_t = 0., uX_t = 0., rf_t = 0., vir_t = 0.;
 	uint16_t* const mylist = lst + tid;
 	for (uint32_t base = 0; base < n_i; base += NT) {  // one pass unless the brick holds more than 256 molecules
-		const uint32_t it = base + (uint32_t)tid;
-		if (it >= n_i) continue;
+		const uint32_t slot_i = base + (uint32_t)tid;
+		if (slot_i >= n_i) continue;
+		const uint32_t it = by_comp ? (uint32_t)oord[slot_i] : slot_i;
 		int lo = 0, hi = NBC;
 		while (hi - lo > 1) {
 			const int mid = (lo + hi) >> 1;
@@ -141,33 +200,31 @@ __global__ void __launch_bounds__(MTPB) k_force_ms_brick(ForceParams P, int nbx,
 				const Rot Rj = HAS_ROT ? rot_of(sq0[j], sq1[j], sq2[j], sq3[j]) : rot_of(1., 0., 0., 0.);
 				mol_pair<WITH_VI>(*P.ct, ci, ri, Ri, (int)scid[j], rj, Rj, drm, dot(drm, drm) < rclj2, 0.5, acc);
 			};
-			// ---- phase 1 ---------------------------------------------------------------------------------------------------
-			uint32_t cnt = 0;
-			for (int row = 0; row < NROWS; ++row) {
-				const int r0 = rowbase + (row / NW) * (RY * RX) + (row % NW) * RX;
-				const uint32_t jb = cstart[r0], je = cstart[r0 + NW];
-				for (uint32_t j = jb; j < je; ++j) {
-					const double dx = ri.x - sx[j], dy = ri.y - sy[j], dz = ri.z - sz[j];
-					const double dd = dx * dx + dy * dy + dz * dz;
-					const bool hit = (dd < rc2) & (dd != 0.);  // dd == 0: the molecule itself
-					mylist[(hit ? min(cnt, (uint32_t)CAPL) : (uint32_t)CAPL) * NT] = (uint16_t)j;
-					cnt += hit ? 1u : 0u;
-				}
-			}
-			// ---- phase 2 ---------------------------------------------------------------------------------------------------
-			if (cnt <= (uint32_t)CAPL) {
-				for (uint32_t s = 0; s < cnt; ++s) pair(mylist[s * NT]);
-			} else {
+			// Phase 1 / phase 2 in windows of CAPL hits (one window unless the neighbourhood is very dense): the walk over
+			// the 9 neighbour rows appends the hits number [done, done + CAPL) to the per-lane list, the molecule-pair body
+			// runs over the list.  The body is instantiated ONCE (it is large: a second inlined copy for an overflow path
+			// doubled the kernel's time through instruction-cache misses).  Hits are processed in candidate order, i.e.
+			// the generic kernel's summation order: results are bitwise the same.
+			uint32_t done = 0, seen;
+			do {
+				seen = 0;
+				uint32_t cnt = 0;
 				for (int row = 0; row < NROWS; ++row) {
 					const int r0 = rowbase + (row / NW) * (RY * RX) + (row % NW) * RX;
 					const uint32_t jb = cstart[r0], je = cstart[r0 + NW];
 					for (uint32_t j = jb; j < je; ++j) {
 						const double dx = ri.x - sx[j], dy = ri.y - sy[j], dz = ri.z - sz[j];
 						const double dd = dx * dx + dy * dy + dz * dz;
-						if ((dd < rc2) & (dd != 0.)) pair(j);
+						const bool hit = (dd < rc2) & (dd != 0.);  // dd == 0: the molecule itself
+						const bool take = hit & (seen >= done) & (seen < done + (uint32_t)CAPL);
+						mylist[(take ? seen - done : (uint32_t)CAPL) * NT] = (uint16_t)j;
+						cnt += take ? 1u : 0u;
+						seen += hit ? 1u : 0u;
 					}
 				}
-			}
+				for (uint32_t s = 0; s < cnt; ++s) pair(mylist[s * NT]);
+				done += cnt;
+			} while (seen > done);
 		} else {
 			// shell does not fit the staging area: same walk straight from global memory
 			const V3 ri = {P.x[gi], P.y[gi], P.z[gi]};
@@ -253,12 +310,12 @@ bool launch_force_ms(const ForceParams& p, bool with_vi, bool has_rot, hipStream
 					 double mean_per_cell, BrickLists* bl) {
 	if (p.g.hw != 1 || p.ct == nullptr) return false;
 	const double m = mean_per_cell * 1.08;
-	const double cs = has_rot ? 1080. : 2470., cd = has_rot ? 800. : 1800.;
-	if (m * (10 * 6 * 6) <= cs) return launch_ms<8, 4, 4, 1080, 2470, 31>(p, bl, with_vi, has_rot, s, nblocks, partials_cap);
-	if (m * (6 * 6 * 6) <= cs) return launch_ms<4, 4, 4, 1080, 2470, 31>(p, bl, with_vi, has_rot, s, nblocks, partials_cap);
-	if (m * (6 * 6 * 4) <= cd) return launch_ms<4, 4, 2, 800, 1800, 63>(p, bl, with_vi, has_rot, s, nblocks, partials_cap);
-	if (m * (6 * 4 * 4) <= cd) return launch_ms<4, 2, 2, 800, 1800, 63>(p, bl, with_vi, has_rot, s, nblocks, partials_cap);
-	if (m * (4 * 4 * 4) <= cd) return launch_ms<2, 2, 2, 800, 1800, 63>(p, bl, with_vi, has_rot, s, nblocks, partials_cap);
+	const double cs = has_rot ? 1050. : 2400., cd = has_rot ? 770. : 1730.;
+	if (m * (10 * 6 * 6) <= cs) return launch_ms<8, 4, 4, 1050, 2400, 31>(p, bl, with_vi, has_rot, s, nblocks, partials_cap);
+	if (m * (6 * 6 * 6) <= cs) return launch_ms<4, 4, 4, 1050, 2400, 31>(p, bl, with_vi, has_rot, s, nblocks, partials_cap);
+	if (m * (6 * 6 * 4) <= cd) return launch_ms<4, 4, 2, 770, 1730, 63>(p, bl, with_vi, has_rot, s, nblocks, partials_cap);
+	if (m * (6 * 4 * 4) <= cd) return launch_ms<4, 2, 2, 770, 1730, 63>(p, bl, with_vi, has_rot, s, nblocks, partials_cap);
+	if (m * (4 * 4 * 4) <= cd) return launch_ms<2, 2, 2, 770, 1730, 63>(p, bl, with_vi, has_rot, s, nblocks, partials_cap);
 	return false;
 }
 

@@ -509,13 +509,14 @@ MULTISITE_CASES = [k for k in FORCE_CASES if k not in LJ1_CASES]
 @pytest.mark.parametrize("name", MULTISITE_CASES)
 def test_multisite_brick_kernel_is_bitwise_the_generic_kernel(name):
     """k_force_ms_brick (LDS-staged, default for multi-site component sets) visits the candidates in the order of
-    k_force_generic: F, M, Vi bitwise equal, sums to rounding (different partial-sum grouping)."""
+    k_force_generic (whatever lane a molecule is handed to): F, M, Vi bitwise equal, sums to rounding (different
+    partial-sum grouping)."""
     case = MAN[name]
     ps = inp.read_inp(input_path(case["input"]))
     st = sorted_phase_space(ps)
     gen = run_forces(ps, st, case["rc"], bool(case["periodic"]), kernel=capi.FK_GENERIC)
     brk = run_forces(ps, st, case["rc"], bool(case["periodic"]), kernel=capi.FK_AUTO)
-    for k in ("F", "M", "Vi"):
+    for k in ("F", "M", "Vi"):  # candidates are visited in the generic kernel's order: bitwise
         assert np.array_equal(gen[k], brk[k]), k
     assert abs(gen["upot"] - brk["upot"]) <= 1e-13 * max(abs(gen["upot"]), 1e-300) + 1e-300
     assert abs(gen["virial"] - brk["virial"]) <= 1e-13 * max(abs(gen["virial"]), 1e-300) + 1e-300

@@ -40,6 +40,8 @@ def mixed_bcc(ps, n):
     q /= np.linalg.norm(q, axis=1)[:, None]
     ncomp = len(ps.components.components)
     cid = (np.arange(N) % ncomp).astype(np.int32)
+    if os.environ.get("LS1_MS_SLABS"):  # diagnostic: components in slabs along x -> (almost) uniform component per brick
+        cid = np.minimum((r[:, 0] / L * ncomp).astype(np.int32), ncomp - 1)
     return np.array([L, L, L]), r, np.zeros((N, 3)), q, np.zeros((N, 3)), cid, np.arange(1, N + 1, dtype=np.uint64)
 
 

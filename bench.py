@@ -247,6 +247,7 @@ def main():
     # whole step per GPU: plain = force 48 + integrator 120 + re-bin 124 = 292 B; fused = 96 + 124 = 220 B per molecule
     step_bytes_total = n_local * ((FUSED_BYTES_PER_MOLECULE + 124.0) * n_fused + STEP_BYTES_PER_MOLECULE * (args.steps - n_fused))
     traffic = None
+    pmc_extra = {}
     try:
         with open(os.path.join(ROOT, "profiles", PMC_SUMMARY)) as fh:
             js = json.load(fh)
@@ -255,6 +256,8 @@ def main():
                 e.get_option("force_kernel") in (0, 2) and e.get_option("lj_split") == 0 and \
                 abs(pm["algorithmic_bytes_per_launch"] / alg_bytes_per_launch - 1.0) < 0.03:
             traffic = pm["traffic_bytes_per_launch"]
+            pmc_extra = {k: pm[k] for k in ("fp64_flop_per_launch", "valu_busy_frac_per_simd", "mfma_busy_frac",
+                                            "lds_busy_frac_per_cu", "l2_hit_rate") if k in pm}
     except Exception:
         traffic = None
     if rank == 0:
@@ -281,6 +284,16 @@ def main():
                                    "rebin": rebin_ms / args.steps, "halo": halo_ms / args.steps},
             "last_step": {k: (float(v_) if not isinstance(v_, int) else v_) for k, v_ in last.items()} if isinstance(last, dict) else None,
         }
+        if pmc_extra:
+            # the kernel is issue-bound, not HBM-bound: the FP64 vector rate actually sustained (PMC instruction counts
+            # of this workload, profiles/, over the live launch time) next to the 78.6 TFLOP/s FP64 vector peak, and the
+            # pipe utilisations of the same PMC passes
+            comp = {"fp64_vector_peak_tflops": 78.6}
+            if "fp64_flop_per_launch" in pmc_extra:
+                comp["fp64_tflops"] = pmc_extra["fp64_flop_per_launch"] / avg_force_s / 1e12
+                comp["fp64_frac"] = comp["fp64_tflops"] / 78.6
+            comp.update({k: v for k, v in pmc_extra.items() if k != "fp64_flop_per_launch"})
+            out["roofline"]["compute"] = comp
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

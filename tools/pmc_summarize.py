@@ -62,6 +62,10 @@ if fk:
         fs["valu_lane_insts_per_molecule"] = k["SQ_INSTS_VALU"] * 64.0 / n
         f64 = sum(k.get(c, 0.0) for c in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64"))
         fs["fp64_arith_share_of_valu"] = f64 / k["SQ_INSTS_VALU"]
+        # FP64 vector work actually issued (lane operations, FMA = 2): the compute-side ceiling of this kernel is the
+        # 78.6 TFLOP/s FP64 vector rate, not HBM
+        fs["fp64_flop_per_launch"] = 64.0 * (2.0 * k.get("SQ_INSTS_VALU_FMA_F64", 0.0) + k.get("SQ_INSTS_VALU_ADD_F64", 0.0) +
+                                             k.get("SQ_INSTS_VALU_MUL_F64", 0.0))
     summary["force_kernel"] = fs
 json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary.get("force_kernel", {}), indent=1))

@@ -68,6 +68,8 @@ const char* ls1hip_version(void);
  * "deterministic" (0|1 canonical in-cell order by molecule id),
  * "count_pairs" (0|1 tally molecule pairs / site interactions inside the cutoff for ls1hip_pair_stats — the
  * counters of adapter/FlopCounter.cpp:20-76; forces then use the generic kernel),
+ * "last_force_kernel" (read only: kernel family of the last force launch — 1 generic, 2 single-centre LJ brick kernels,
+ *   3 multi-site brick kernel; lets callers / tests see a fallback to the generic kernel),
  * "fuse_integration" (0|1, default 1: ls1hip_run lets the force pass do the integration between steps, see
  * ls1hip_forces_kick_drift), "can_fuse_integration" (read only),
  * "lj_split" (variant of the single-centre LJ fast path; results are the same to rounding, only speed differs:

@@ -217,6 +217,7 @@ extern "C" int ls1hip_get_option(const ls1hip_ctx* c, const char* name, long* v)
 	else if (n == "lj_split") *v = c->opt_lj_split;
 	else if (n == "fuse_integration") *v = c->opt_fuse;
 	else if (n == "can_fuse_integration") *v = can_fuse(c) ? 1 : 0;
+	else if (n == "last_force_kernel") *v = c->last_force_kernel;
 	else return LS1HIP_EINVAL;
 	return LS1HIP_OK;
 }
@@ -441,7 +442,12 @@ static int alloc_mol(ls1hip_ctx* c, size_t n) {
 	size_t cap_real = (size_t)(n * (c->has_remote ? 1.25 : 1.0)) + 1024;
 	size_t cap_halo = (size_t)(dens * (vol_out - vol) * 1.6) + 4096;
 	cap_halo = std::min(cap_halo, 26 * n + 4096);
-	if (cap_real <= c->cap_real && cap_halo <= c->cap_halo) return 0;
+	// per-workgroup partial sums: the generic kernels launch cap_real / 128 workgroups, the brick kernels one per brick;
+	// the smallest brick is 8 cells (1x4x2 or 2x2x2), rounded up per dimension, + 16 for the XCD-aligned grid.  (Sized by
+	// molecules only, small / sparse boxes silently fell back to the generic kernel: found by the random-box sweep.)
+	const size_t max_bricks = (size_t)c->g.box[0] * ((c->g.box[1] + 1) / 2) * ((c->g.box[2] + 1) / 2) + 16;
+	const size_t partials_cap = std::max(cap_real / 64 + 16, max_bricks);
+	if (cap_real <= c->cap_real && cap_halo <= c->cap_halo && partials_cap <= c->partials_cap) return 0;
 	free_mol(c);
 	const size_t tot = cap_real + cap_halo;
 	int rc = 0;
@@ -474,7 +480,7 @@ static int alloc_mol(ls1hip_ctx* c, size_t n) {
 		(rc = dalloc(c, &c->d_perm, std::max(cap_real, cap_halo))) || (rc = dalloc(c, &c->d_ckey, cap_real)) ||
 		(rc = dalloc(c, &c->d_idk, cap_real));
 	if (rc) return rc;
-	c->partials_cap = cap_real / 64 + 16;
+	c->partials_cap = partials_cap;
 	if ((rc = dalloc(c, &c->d_partials, c->partials_cap * 4))) return rc;
 	// export slices per remote direction, sized from the geometry of the region that feeds the direction
 	uint32_t offL = 0, offH = 0;
@@ -752,6 +758,7 @@ static int launch_forces(ls1hip_ctx* c, int which, bool fuse = false, double dt 
 							   &c->brick_lists);
 	}
 	if (!done && fuse) FAIL(c, LS1HIP_EINVAL, "fused force + integration needs the single-centre LJ fast path");
+	c->last_force_kernel = done ? (c->one_clj ? LS1HIP_FK_LDS_LIST : 3) : LS1HIP_FK_GENERIC;
 	if (!done) {
 		launch_force_generic(P, c->one_clj, c->opt_vi != 0, c->h_ct.has_rot != 0, c->stream, &nblocks);
 	}

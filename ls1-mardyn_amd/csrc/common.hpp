@@ -106,6 +106,7 @@ struct ls1hip_ctx {
 	// options
 	long opt_force_kernel = LS1HIP_FK_AUTO, opt_cic = 1, opt_vi = 0, opt_det = 1, opt_count_pairs = 0, opt_lj_split = 0;
 	ls1::BrickLists brick_lists;
+	long last_force_kernel = 0;  // family of the last force launch: 1 generic, 2 LJ brick kernels, 3 multi-site brick kernel
 	long opt_fuse = 1;       // ls1hip_run: fuse force + integration between steps when possible
 	bool pos_in_F = false;   // positions of the owned molecules live in frc.F* (after a fused force pass)
 	int fused_split = 0;     // a fused which=1 pass is waiting for its which=2 pass

@@ -52,6 +52,9 @@ def run_forces(ps, st, rc, periodic, kernel=0, vi=True, cic=1, split=2):
     out["upot"] = dom.getLocalUpot()
     out["virial"] = dom.getLocalVirial()
     out["container"] = cont
+    out["kernel_family"] = cont.engine.get_option("last_force_kernel")
+    if kernel == capi.FK_LDS_LIST and not vi:
+        assert out["kernel_family"] == 2, "the LJ fast path was requested but the generic kernel ran"
     return out
 
 
@@ -516,6 +519,7 @@ def test_multisite_brick_kernel_is_bitwise_the_generic_kernel(name):
     st = sorted_phase_space(ps)
     gen = run_forces(ps, st, case["rc"], bool(case["periodic"]), kernel=capi.FK_GENERIC)
     brk = run_forces(ps, st, case["rc"], bool(case["periodic"]), kernel=capi.FK_AUTO)
+    assert gen["kernel_family"] == 1 and brk["kernel_family"] == 3  # generic vs multi-site brick kernel, really
     for k in ("F", "M", "Vi"):  # candidates are visited in the generic kernel's order: bitwise
         assert np.array_equal(gen[k], brk[k]), k
     assert abs(gen["upot"] - brk["upot"]) <= 1e-13 * max(abs(gen["upot"]), 1e-300) + 1e-300
@@ -578,3 +582,42 @@ def test_homogeneous_long_range_correction(name):
     u, v = cont.engine.long_range_homogeneous(nmol, len(ps.ids) / float(np.prod(ps.length)))
     assert abs(u - g["lrc"][0]) <= 1e-12 * max(abs(g["lrc"][0]), abs(g["upot"]))
     assert abs(v - g["lrc"][1]) <= 1e-12 * max(abs(g["lrc"][1]), abs(g["virial"]))
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_lj_fast_path_random_boxes(seed):
+    """Randomised sweep of the 1CLJ fast path against the generic kernel: non-cubic boxes with 3..14 cells per
+    dimension (every partial-brick combination of the 1x4x4 / 1x4x2 pencil bricks and of the 4x2x2 list bricks),
+    densities 0.2..1.1, cutoff 1.8..3.2, random positions with a minimum distance, all lj_split variants and the fused /
+    split passes.  Forces to 1e-12 of the largest force, U_pot / virial to 1e-11."""
+    rng = np.random.default_rng(1000 + seed)
+    rc = float(rng.uniform(1.8, 3.2))
+    ncell = rng.integers(3, 15, 3)
+    L = ncell * rc * rng.uniform(1.0, 1.18, 3)  # floor(L / rc) == ncell
+    rho = float(rng.uniform(0.2, 1.1))
+    N = int(rho * np.prod(L))
+    # jittered simple-cubic start keeps a minimum distance at every density
+    m = np.ceil((N / np.prod(L)) ** (1 / 3) * L).astype(int)
+    g = np.stack(np.meshgrid(*[np.arange(k) for k in m], indexing="ij"), -1).reshape(-1, 3)
+    sel = rng.permutation(len(g))[:N]
+    a = L / m
+    r = ((g[sel] + 0.5) * a + rng.uniform(-0.2, 0.2, (N, 3)) * a) % L
+    comp = inp.ComponentSet([inp.make_component(lj=[(0, 0, 0, 1, 1.3, 0.9, rc, int(seed % 2))])], np.zeros((0, 2)), 1e10)
+    ps = inp.PhaseSpace(comp, L, np.arange(1, N + 1, dtype=np.uint64), np.zeros(N, np.int32), r, np.zeros((N, 3)),
+                        np.tile([1., 0, 0, 0], (N, 1)), np.zeros((N, 3)))
+    st = sorted_phase_space(ps)
+    gen = run_forces(ps, st, rc, True, kernel=capi.FK_GENERIC, vi=False)
+    fmax = np.max(np.abs(gen["F"]))
+    for cic, split in ((1, 0), (1, 4), (1, 6), (1, 2), (2, 0)):
+        out = run_forces(ps, st, rc, True, kernel=capi.FK_LDS_LIST, vi=False, cic=cic, split=split)
+        assert np.max(np.abs(out["F"] - gen["F"])) < 1e-12 * fmax, (cic, split, ncell.tolist(), rho)
+        assert abs(out["upot"] - gen["upot"]) <= 1e-11 * abs(gen["upot"]), (cic, split)
+        assert abs(out["virial"] - gen["virial"]) <= 1e-11 * abs(gen["virial"]), (cic, split)
+        if cic == 1 and split == 0:  # inner + boundary passes == full pass, bitwise
+            cont = out["container"]
+            dom = mirror.Domain(ps.length)
+            cp = mirror.VectorizedCellProcessor(dom, rc, rc)
+            cont.traversePartialInnermostCells(cp, 0, 1)
+            cont.traverseNonInnermostCells(cp)
+            mol = cont.molecules()
+            assert np.array_equal(cont.forces()["F"][np.argsort(mol["ids"])], out["F"])

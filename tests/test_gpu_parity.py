@@ -621,3 +621,41 @@ def test_lj_fast_path_random_boxes(seed):
             cont.traverseNonInnermostCells(cp)
             mol = cont.molecules()
             assert np.array_equal(cont.forces()["F"][np.argsort(mol["ids"])], out["F"])
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_multisite_brick_random_boxes(seed):
+    """Randomised sweep of the multi-site brick kernel against the generic kernel (bitwise F, M, Vi): non-cubic boxes with
+    3..12 cells per dimension, 0.5..14 molecules per cell (every brick shape from 8x4x4 to 2x2x2, and the generic
+    fallback above that), the five-component multipole set (massless components included: statics only) or ethane,
+    random orientations."""
+    rng = np.random.default_rng(2000 + seed)
+    if seed % 3 == 2:
+        comps = inp.read_inp(input_path(MAN["ethan"]["input"])).components
+        rc = 32.1254
+    else:
+        comps = inp.read_inp(input_path("VectorizationMultiComponentMultiPotentials.inp")).components
+        rc = 35.0
+    ncomp = len(comps.components)
+    ncell = rng.integers(3, 13, 3)
+    L = ncell * rc * rng.uniform(1.0, 1.08, 3)
+    per_cell = float(np.exp(rng.uniform(np.log(0.5), np.log(14.0))))
+    N = max(int(per_cell * np.prod(ncell)), 8)
+    m = np.ceil((N / np.prod(L)) ** (1 / 3) * L).astype(int)
+    g = np.stack(np.meshgrid(*[np.arange(k) for k in m], indexing="ij"), -1).reshape(-1, 3)
+    sel = rng.permutation(len(g))[:N]
+    N = len(sel)
+    a = L / m
+    r = ((g[sel] + 0.5) * a + rng.uniform(-0.25, 0.25, (N, 3)) * a) % L
+    q = rng.normal(size=(N, 4)); q /= np.linalg.norm(q, axis=1)[:, None]
+    cid = rng.integers(0, ncomp, N).astype(np.int32)
+    ps = inp.PhaseSpace(comps, L, np.arange(1, N + 1, dtype=np.uint64), cid, r, np.zeros((N, 3)), q, np.zeros((N, 3)))
+    st = sorted_phase_space(ps)
+    gen = run_forces(ps, st, rc, True, kernel=capi.FK_GENERIC)
+    brk = run_forces(ps, st, rc, True, kernel=capi.FK_AUTO)
+    assert gen["kernel_family"] == 1
+    assert brk["kernel_family"] == (3 if per_cell * 64 * 1.08 <= 770 else brk["kernel_family"])
+    for k in ("F", "M", "Vi"):
+        assert np.array_equal(gen[k], brk[k]), (k, ncell.tolist(), per_cell)
+    assert abs(gen["upot"] - brk["upot"]) <= 1e-12 * abs(gen["upot"]) + 1e-300
+    assert abs(gen["virial"] - brk["virial"]) <= 1e-12 * abs(gen["virial"]) + 1e-300

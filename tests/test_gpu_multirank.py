@@ -291,3 +291,44 @@ def test_multisite_subboxes_equal_single_domain(world):
     assert np.max(np.abs(dr)) < 1e-9
     for k in ("v", "q", "D"):
         assert np.max(np.abs(a1[k] - b1[k])) < 1e-9 * max(np.max(np.abs(a1[k])), 1e-300), k
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_decompositions_equal_single_domain(seed):
+    """Randomised: non-cubic boxes, rank grids (2,1,1) ... (2,2,2) in any orientation, both call orders, forces and a few
+    hot steps (migration across faces, edges and corners) against the single domain."""
+    rng = np.random.default_rng(3000 + seed)
+    rc = 2.5
+    grid = tuple(int(x) for x in rng.permutation([(2, 1, 1), (2, 2, 1), (2, 2, 2), (4, 1, 1), (4, 2, 1)][seed % 5]))
+    world = int(np.prod(grid))
+    ncell = np.array([int(rng.integers(3, 6)) * g for g in grid])  # >= 3 cells per sub-box and dimension
+    L = ncell * rc * rng.uniform(1.01, 1.12, 3)
+    rho = 0.6
+    N = int(rho * np.prod(L))
+    m = np.ceil((N / np.prod(L)) ** (1 / 3) * L).astype(int)
+    g = np.stack(np.meshgrid(*[np.arange(k) for k in m], indexing="ij"), -1).reshape(-1, 3)
+    sel = rng.permutation(len(g))[:N]
+    N = len(sel)
+    a = L / m
+    r = ((g[sel] + 0.5) * a + rng.uniform(-0.2, 0.2, (N, 3)) * a) % L
+    v = rng.normal(0, 3.0, (N, 3)); v -= v.mean(0)
+    ids = np.arange(1, N + 1, dtype=np.uint64)
+    comps = inp.ComponentSet([inp.make_component(lj=[(0, 0, 0, 1, 1, 1, rc, 0)])], np.zeros((0, 2)), 1e10)
+    single = InProcessCluster(1, comps, rc, L, ids, r, v)
+    multi = InProcessCluster(world, comps, rc, L, ids, r, v, grid)
+    multi.overlap_order = bool(seed % 2)
+    t1 = single.forces(split=False)
+    tm = multi.forces()
+    a1, b1 = single.gather(), multi.gather()
+    assert np.array_equal(a1["ids"], b1["ids"])
+    assert np.max(np.abs(a1["F"] - b1["F"])) < 1e-12 * np.max(np.abs(a1["F"])), (grid, ncell.tolist())
+    assert np.allclose(t1, tm, rtol=1e-12)
+    for _ in range(4):
+        single.step(0.004)
+        multi.step(0.004)
+    a1, b1 = single.gather(), multi.gather()
+    assert np.array_equal(a1["ids"], b1["ids"])
+    dr = a1["r"] - b1["r"]
+    dr -= L * np.round(dr / L)
+    assert np.max(np.abs(dr)) < 1e-10
+    assert np.max(np.abs(a1["v"] - b1["v"])) < 1e-10 * np.max(np.abs(a1["v"]))

@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="force kernel variant (LS1HIP_FK_*)")
     ap.add_argument("--cic", type=int, default=0, help="cells in cutoff (0 = engine default)")
     ap.add_argument("--split", type=int, default=0, help="lanes per molecule in the LDS LJ kernel (0 = engine default)")
+    ap.add_argument("--overlap", type=int, default=-1, help="ls1hip_run halo mode: 0 single pass, 1 overlapped, 2 split sequential")
     ap.add_argument("--no-fuse", action="store_true", help="separate integrator passes instead of the fused force pass")
     ap.add_argument("--decomp", action="store_true",
                     help="diagnostic: run the decomposed (multi-rank) step loop even with one rank")
@@ -204,6 +205,8 @@ def main():
 
     if args.no_fuse:
         (sim.engine if sim is not None else eng).set_option("fuse_integration", 0)
+    if args.overlap >= 0:
+        (sim.engine if sim is not None else eng).set_option("overlap_halo", args.overlap)
 
     def run(k):
         if sim is not None:

@@ -70,6 +70,9 @@ const char* ls1hip_version(void);
  * counters of adapter/FlopCounter.cpp:20-76; forces then use the generic kernel),
  * "last_force_kernel" (read only: kernel family of the last force launch — 1 generic, 2 single-centre LJ brick kernels,
  *   3 multi-site brick kernel; lets callers / tests see a fallback to the generic kernel),
+ * "overlap_halo" (ls1hip_run: 0 = halo, then one traversal of all cells (default, fastest on a single GPU); 1 = inner
+ *   cells first, the halo built on a second stream meanwhile, then the boundary cells — the order a transport-driven
+ *   multi-rank loop uses; 2 = halo, inner cells, boundary cells on one stream),
  * "fuse_integration" (0|1, default 1: ls1hip_run lets the force pass do the integration between steps, see
  * ls1hip_forces_kick_drift), "can_fuse_integration" (read only),
  * "lj_split" (variant of the single-centre LJ fast path; results are the same to rounding, only speed differs:

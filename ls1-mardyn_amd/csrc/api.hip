@@ -197,6 +197,9 @@ extern "C" int ls1hip_set_option(ls1hip_ctx* c, const char* name, long v) {
 		c->opt_count_pairs = v ? 1 : 0;
 	} else if (n == "fuse_integration") {
 		c->opt_fuse = v ? 1 : 0;
+	} else if (n == "overlap_halo") {
+		REQUIRE(c, v >= 0 && v <= 2, "overlap_halo must be 0, 1 or 2");
+		c->opt_overlap_halo = v;
 	} else if (n == "lj_split") {
 		REQUIRE(c, v == 0 || v == 1 || v == 2 || v == 4 || v == 5 || v == 6, "lj_split must be 0 (auto), 1, 2 (list kernel lanes per molecule), 4, 5 or 6 (MFMA pre-filter variants)");
 		c->opt_lj_split = v;
@@ -216,6 +219,7 @@ extern "C" int ls1hip_get_option(const ls1hip_ctx* c, const char* name, long* v)
 	else if (n == "count_pairs") *v = c->opt_count_pairs;
 	else if (n == "lj_split") *v = c->opt_lj_split;
 	else if (n == "fuse_integration") *v = c->opt_fuse;
+	else if (n == "overlap_halo") *v = c->opt_overlap_halo;
 	else if (n == "can_fuse_integration") *v = can_fuse(c) ? 1 : 0;
 	else if (n == "last_force_kernel") *v = c->last_force_kernel;
 	else return LS1HIP_EINVAL;
@@ -1032,10 +1036,24 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 			// post-force kick of step s-1 fused with the pre-force kick+drift of step s (same F, one pass)
 			if ((rc = ls1hip_kick_then_kick_drift(c, dt))) return rc;
 		}
-		if ((rc = ls1hip_rebin(c)) || (rc = ls1hip_halo(c))) return rc;
+		if ((rc = ls1hip_rebin(c))) return rc;
 		advanced = fuse && s + 1 < nsteps;
-		if (advanced) rc = ls1hip_forces_kick_drift(c, 0, dt, nullptr, nullptr);
-		else rc = ls1hip_forces(c, 0, nullptr, nullptr);
+		if (c->opt_overlap_halo == 2) {
+			// halo first, then the inner and the boundary cells as two passes of the same stream
+			if ((rc = ls1hip_halo(c))) return rc;
+			rc = advanced ? ls1hip_forces_kick_drift(c, 1, dt, nullptr, nullptr) : ls1hip_forces(c, 1, nullptr, nullptr);
+			if (rc) return rc;
+			rc = advanced ? ls1hip_forces_kick_drift(c, 2, dt, nullptr, nullptr) : ls1hip_forces(c, 2, nullptr, nullptr);
+		} else if (c->opt_overlap_halo) {
+			// inner-cell pass first (it needs the owned molecules only); the periodic images are generated and sorted
+			// on the second stream while it runs; the boundary pass waits for them on the device
+			rc = advanced ? ls1hip_forces_kick_drift(c, 1, dt, nullptr, nullptr) : ls1hip_forces(c, 1, nullptr, nullptr);
+			if (rc || (rc = ls1hip_halo(c))) return rc;
+			rc = advanced ? ls1hip_forces_kick_drift(c, 2, dt, nullptr, nullptr) : ls1hip_forces(c, 2, nullptr, nullptr);
+		} else {
+			if ((rc = ls1hip_halo(c))) return rc;
+			rc = advanced ? ls1hip_forces_kick_drift(c, 0, dt, nullptr, nullptr) : ls1hip_forces(c, 0, nullptr, nullptr);
+		}
 		if (rc) return rc;
 		if (s + 1 == nsteps) {
 			if ((rc = ls1hip_kick(c, 0.5 * dt, nullptr, nullptr, nullptr, nullptr))) return rc;

@@ -49,14 +49,18 @@ struct BrickSel {
 };
 template <int HW, int BX, int BY, int BZ>
 __device__ __forceinline__ BrickSel brick_select(const ForceParams& P, int nbx, int nby, int nbz) {
-	const int nb = P.brick_list ? (int)P.n_list : nbx * nby * nbz;
+	const int nb = P.inner_box ? P.inner_n[0] * P.inner_n[1] * P.inner_n[2] : (P.brick_list ? (int)P.n_list : nbx * nby * nbz);
 	const int chunk = gridDim.x / 8;
 	const int slot = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
 	BrickSel b;
 	b.live = slot < nb;
-	const int brick = (b.live && P.brick_list) ? (int)P.brick_list[slot] : slot;
 	int bx = 0, by = 0, bz = 0;
-	if (b.live) {
+	if (b.live && P.inner_box) {
+		bx = P.inner_lo[0] + slot % P.inner_n[0];
+		by = P.inner_lo[1] + (slot / P.inner_n[0]) % P.inner_n[1];
+		bz = P.inner_lo[2] + slot / (P.inner_n[0] * P.inner_n[1]);
+	} else if (b.live) {
+		const int brick = P.brick_list ? (int)P.brick_list[slot] : slot;
 		bx = brick % nbx;
 		by = (brick / nbx) % nby;
 		bz = brick / (nbx * nby);
@@ -67,7 +71,7 @@ __device__ __forceinline__ BrickSel brick_select(const ForceParams& P, int nbx, 
 	b.ex = min(BX, P.g.dims[0] - HW - b.x0);
 	b.ey = min(BY, P.g.dims[1] - HW - b.y0);
 	b.ez = min(BZ, P.g.dims[2] - HW - b.z0);
-	if (b.live && P.which != 0 && !P.brick_list) {
+	if (b.live && P.which != 0 && !P.brick_list && !P.inner_box) {
 		const bool inner = b.x0 >= 2 * HW && b.y0 >= 2 * HW && b.z0 >= 2 * HW && b.x0 + b.ex <= P.g.dims[0] - 2 * HW &&
 						   b.y0 + b.ey <= P.g.dims[1] - 2 * HW && b.z0 + b.ez <= P.g.dims[2] - 2 * HW;
 		b.live = (P.which == 1) ? inner : !inner;

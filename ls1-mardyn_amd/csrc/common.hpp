@@ -67,8 +67,11 @@ struct ForceParams {
 	int which;         // 0 all, 1 inner cells, 2 boundary cells, 3 all non-halo cells (seam A)
 	uint32_t n_fixed;  // if != 0: number of molecules (overrides cnt->n_real; seam A)
 	int count_pairs;
-	const uint32_t* brick_list;  // LJ brick kernels: bricks of this pass (inner / boundary), nullptr = all bricks
+	const uint32_t* brick_list;  // brick kernels: bricks of this pass (boundary), nullptr = all bricks / inner box
 	uint32_t n_list;
+	// inner pass: the inner bricks form a box of bricks [lo, lo + n) per dimension — indexed arithmetically (a list lookup
+	// puts a dependent global load in front of every workgroup: ~1 us x 105 rounds on the 2.4 ms inner pass)
+	int inner_box, inner_lo[3], inner_n[3];
 	// fused force -> kick -> kick -> drift (LJ fast path only): v updated in place, new positions written to Fx/Fy/Fz
 	int fuse;
 	double dt, dt_inv2m;
@@ -107,6 +110,9 @@ struct ls1hip_ctx {
 	long opt_force_kernel = LS1HIP_FK_AUTO, opt_cic = 1, opt_vi = 0, opt_det = 1, opt_count_pairs = 0, opt_lj_split = 0;
 	ls1::BrickLists brick_lists;
 	long last_force_kernel = 0;  // family of the last force launch: 1 generic, 2 LJ brick kernels, 3 multi-site brick kernel
+	// ls1hip_run halo mode: 0 halo, then one pass over all cells (fastest on one GPU: measured 3.50 / 3.52 / 3.60 ms for
+	// modes 0 / 1 / 2); 1 inner-cell pass first with the halo phase on the second stream meanwhile; 2 halo, inner, boundary
+	long opt_overlap_halo = 0;
 	long opt_fuse = 1;       // ls1hip_run: fuse force + integration between steps when possible
 	bool pos_in_F = false;   // positions of the owned molecules live in frc.F* (after a fused force pass)
 	int fused_split = 0;     // a fused which=1 pass is waiting for its which=2 pass

@@ -683,9 +683,29 @@ long plan_bricks(ForceParams& p, BrickLists* bl, int BX, int BY, int BZ, int nbx
 	long n = (long)nbx * nby * nbz;
 	p.brick_list = nullptr;
 	p.n_list = 0;
-	if ((p.which == 1 || p.which == 2) && brick_lists_for(bl, p.g, BX, BY, BZ, nbx, nby, nbz)) {
-		p.brick_list = bl->d[p.which - 1];
-		p.n_list = bl->n[p.which - 1];
+	p.inner_box = 0;
+	if (p.which == 1) {
+		// "inner" is separable per dimension: bricks [lo, lo + cnt) whose cells lie in [2hw, dims - 2hw)
+		const int B[3] = {BX, BY, BZ}, nbd[3] = {nbx, nby, nbz};
+		const int hw = p.g.hw;
+		n = 1;
+		for (int d = 0; d < 3; ++d) {
+			int lo = nbd[d], hi = -1;
+			for (int b = 0; b < nbd[d]; ++b) {
+				const int x0 = hw + b * B[d], e = std::min(B[d], p.g.dims[d] - hw - x0);
+				if (x0 >= 2 * hw && x0 + e <= p.g.dims[d] - 2 * hw) {
+					lo = std::min(lo, b);
+					hi = std::max(hi, b);
+				}
+			}
+			p.inner_lo[d] = lo;
+			p.inner_n[d] = hi >= lo ? hi - lo + 1 : 0;
+			n *= p.inner_n[d];
+		}
+		p.inner_box = 1;
+	} else if (p.which == 2 && brick_lists_for(bl, p.g, BX, BY, BZ, nbx, nby, nbz)) {
+		p.brick_list = bl->d[1];
+		p.n_list = bl->n[1];
 		n = p.n_list;
 	}
 	return 8 * ((n + 7) / 8);

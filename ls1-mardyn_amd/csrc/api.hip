@@ -450,7 +450,7 @@ static int alloc_mol(ls1hip_ctx* c, size_t n) {
 	// the smallest brick is 8 cells (1x4x2 or 2x2x2), rounded up per dimension, + 16 for the XCD-aligned grid.  (Sized by
 	// molecules only, small / sparse boxes silently fell back to the generic kernel: found by the random-box sweep.)
 	const size_t max_bricks = (size_t)c->g.box[0] * ((c->g.box[1] + 1) / 2) * ((c->g.box[2] + 1) / 2) + 16;
-	const size_t partials_cap = std::max(cap_real / 64 + 16, max_bricks);
+	const size_t partials_cap = std::max(cap_real / 32 + 16, max_bricks);  // generic kernel: up to 4 lanes per molecule, 128 threads
 	if (cap_real <= c->cap_real && cap_halo <= c->cap_halo && partials_cap <= c->partials_cap) return 0;
 	free_mol(c);
 	const size_t tot = cap_real + cap_halo;
@@ -764,7 +764,10 @@ static int launch_forces(ls1hip_ctx* c, int which, bool fuse = false, double dt 
 	if (!done && fuse) FAIL(c, LS1HIP_EINVAL, "fused force + integration needs the single-centre LJ fast path");
 	c->last_force_kernel = done ? (c->one_clj ? LS1HIP_FK_LDS_LIST : 3) : LS1HIP_FK_GENERIC;
 	if (!done) {
-		launch_force_generic(P, c->one_clj, c->opt_vi != 0, c->h_ct.has_rot != 0, c->stream, &nblocks);
+		double vol = 1.;
+		for (int d = 0; d < 3; ++d) vol *= c->g.bmax[d] - c->g.bmin[d];
+		const double nbrs = vol > 0. ? (double)c->n_real / vol * 4.18879 * c->rc * c->rc * c->rc : 0.;
+		launch_force_generic(P, c->one_clj, c->opt_vi != 0, c->h_ct.has_rot != 0, c->stream, &nblocks, nbrs);
 	}
 	launch_force_reduce(c->d_cnt, c->d_partials, nblocks, c->d_stage, c->stream);
 	HIPCHK(c, hipGetLastError());

@@ -214,7 +214,8 @@ struct PackSegments {
 };
 void launch_pack_segments(const PackSegments& seg, const double* src, double* dst, hipStream_t s);
 
-void launch_force_generic(const ForceParams& p, bool one_clj, bool with_vi, bool has_rot, hipStream_t s, uint32_t* nblocks);
+void launch_force_generic(const ForceParams& p, bool one_clj, bool with_vi, bool has_rot, hipStream_t s, uint32_t* nblocks,
+						  double expected_neighbours = 0.);
 // LDS-tiled 1CLJ kernel (kernels_force_lj.hip); returns false if it cannot handle the configuration
 bool launch_force_lj(const ForceParams& p, hipStream_t s, uint32_t* nblocks, double* partials, size_t partials_cap,
 					 int split, double mean_per_cell, BrickLists* bl);

@@ -94,12 +94,17 @@ __device__ __forceinline__ void generic_pair(const ForceParams& P, int ci, const
 // candidate order, so the sums are bitwise those of the single loop.  Neighbourhoods with more hits than the list holds
 // are processed in several windows of the same two phases.
 constexpr int GCAP = 79;  // list entries per lane: (GCAP + 1) x 128 x 4 B = 40 KB -> 4 workgroups (8 waves) / CU, the VGPR limit of the multi-site body
-template <bool ONE_CLJ, bool WITH_VI, bool HAS_ROT>
+// SPLIT = 4 (dense multi-site neighbourhoods): four adjacent lanes share a molecule, lane `part` walks the neighbour cells
+// k = part, part + 4, ...; the four quarter lists together hold ~4 x GCAP hits in ONE window (a single lane would re-scan
+// the ~1000 candidates of liquid ethane once per window of 79 hits), the partial sums are combined by two DPP exchanges.
+template <bool ONE_CLJ, bool WITH_VI, bool HAS_ROT, int SPLIT = 1>
 __global__ void __launch_bounds__(FTPB) k_force_generic(ForceParams P) {
+	static_assert(SPLIT == 1 || (SPLIT == 4 && !ONE_CLJ), "SPLIT = 4 is for the multi-site instantiations");
 	// slot-major; row GCAP = dummy target of misses / overflow.  The single-centre LJ body is as cheap as the list
 	// bookkeeping (measured 5.5 -> 10.5 ms with a list), so ONE_CLJ keeps the single loop and no LDS.
 	__shared__ uint32_t glist[ONE_CLJ ? 1 : (GCAP + 1) * FTPB];
-	const uint32_t p = blockIdx.x * FTPB + threadIdx.x;
+	const uint32_t p = (blockIdx.x * FTPB + threadIdx.x) / SPLIT;
+	const int part = (int)(threadIdx.x % SPLIT);
 	const uint32_t n_real = P.n_fixed ? P.n_fixed : P.cnt->n_real;
 	bool active = p < n_real;
 	int cx = 0, cy = 0, cz = 0;
@@ -163,9 +168,11 @@ __global__ void __launch_bounds__(FTPB) k_force_generic(ForceParams P) {
 			do {
 				seen = 0;
 				uint32_t cnt = 0;
+				int kcell = 0;
 				for (int dz = -hw; dz <= hw; ++dz)
 					for (int dy = -hw; dy <= hw; ++dy)
-						for (int dx = -hw; dx <= hw; ++dx) {
+						for (int dx = -hw; dx <= hw; ++dx, ++kcell) {
+							if (SPLIT > 1 && kcell % SPLIT != part) continue;
 							const int c2 = cell_index(P.g, cx + dx, cy + dy, cz + dz);
 							const uint32_t jb = P.cell_begin[c2], je = P.cell_end[c2];
 							for (uint32_t j = jb; j < je; ++j) {
@@ -189,6 +196,20 @@ __global__ void __launch_bounds__(FTPB) k_force_generic(ForceParams P) {
 			} while (seen > done);
 			nhit = seen;
 		}
+	}
+	if (SPLIT > 1) {
+		// the SPLIT adjacent lanes of a molecule (all active or all inactive) combine their partial sums
+		auto sum4 = [](double v) {
+			v += __shfl_xor(v, 1);
+			v += __shfl_xor(v, 2);
+			return v;
+		};
+		acc.F = {sum4(acc.F.x), sum4(acc.F.y), sum4(acc.F.z)};
+		if (HAS_ROT) acc.M = {sum4(acc.M.x), sum4(acc.M.y), sum4(acc.M.z)};
+		if (WITH_VI) acc.Vi = {sum4(acc.Vi.x), sum4(acc.Vi.y), sum4(acc.Vi.z)};
+		// the macroscopic sums below add every lane's own partial value: no combination needed
+	}
+	if (active && part == 0) {
 		P.Fx[p] = acc.F.x;
 		P.Fy[p] = acc.F.y;
 		P.Fz[p] = acc.F.z;
@@ -211,14 +232,17 @@ __global__ void __launch_bounds__(FTPB) k_force_generic(ForceParams P) {
 	}
 }
 
-template <bool A, bool B, bool C>
+template <bool A, bool B, bool C, int SPLIT = 1>
 static void launch_g(const ForceParams& p, dim3 grid, hipStream_t s) {
-	hipLaunchKernelGGL((k_force_generic<A, B, C>), grid, dim3(FTPB), 0, s, p);
+	hipLaunchKernelGGL((k_force_generic<A, B, C, SPLIT>), grid, dim3(FTPB), 0, s, p);
 }
 
+// expected_neighbours: mean number of molecules within the cutoff (density x 4/3 pi rc^3); above ~60 the multi-site
+// instantiations run with four lanes per molecule (see k_force_generic)
 void launch_force_generic(const ForceParams& p, bool one_clj, bool with_vi, bool has_rot, hipStream_t s,
-						  uint32_t* nblocks) {
-	const uint32_t nb = (p.n_real_cap + FTPB - 1) / FTPB;
+						  uint32_t* nblocks, double expected_neighbours) {
+	const bool split4 = !one_clj && expected_neighbours > 0.75 * GCAP;
+	const uint32_t nb = (uint32_t)(((size_t)p.n_real_cap * (split4 ? 4 : 1) + FTPB - 1) / FTPB);
 	*nblocks = nb;
 	if (nb == 0) return;
 	const dim3 grid(nb);
@@ -226,11 +250,21 @@ void launch_force_generic(const ForceParams& p, bool one_clj, bool with_vi, bool
 		if (with_vi) launch_g<true, true, false>(p, grid, s);
 		else launch_g<true, false, false>(p, grid, s);
 	} else if (has_rot) {
-		if (with_vi) launch_g<false, true, true>(p, grid, s);
-		else launch_g<false, false, true>(p, grid, s);
+		if (split4) {
+			if (with_vi) launch_g<false, true, true, 4>(p, grid, s);
+			else launch_g<false, false, true, 4>(p, grid, s);
+		} else {
+			if (with_vi) launch_g<false, true, true>(p, grid, s);
+			else launch_g<false, false, true>(p, grid, s);
+		}
 	} else {
-		if (with_vi) launch_g<false, true, false>(p, grid, s);
-		else launch_g<false, false, false>(p, grid, s);
+		if (split4) {
+			if (with_vi) launch_g<false, true, false, 4>(p, grid, s);
+			else launch_g<false, false, false, 4>(p, grid, s);
+		} else {
+			if (with_vi) launch_g<false, true, false>(p, grid, s);
+			else launch_g<false, false, false>(p, grid, s);
+		}
 	}
 }
 

@@ -660,3 +660,39 @@ def test_multisite_brick_random_boxes(seed):
         assert np.array_equal(gen[k], brk[k]), (k, ncell.tolist(), per_cell)
     assert abs(gen["upot"] - brk["upot"]) <= 1e-12 * abs(gen["upot"]) + 1e-300
     assert abs(gen["virial"] - brk["virial"]) <= 1e-12 * abs(gen["virial"]) + 1e-300
+
+
+def test_dense_multisite_liquid_four_lanes_per_molecule():
+    """Liquid-density ethane (2CLJ, r_c = 4.9 sigma: ~38 molecules per cell, ~150 neighbours): beyond the brick kernel's
+    staging area, so the generic kernel runs, with four lanes per molecule (quarter lists).  Against the oracle, all cells
+    and the inner / boundary split."""
+    ps0 = inp.read_inp(input_path(MAN["ethan"]["input"]))
+    comps, rc = ps0.components, 32.1254
+    rng = np.random.default_rng(31)
+    n = 13
+    N = 2 * n ** 3
+    rho = 20 * 9826 / 571.607759 ** 3
+    L = (N / rho) ** (1 / 3)
+    a = L / n
+    g = np.stack(np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij"), -1).reshape(-1, 3) * a
+    r = (np.concatenate([g + 0.25 * a, g + 0.75 * a]) + 0.1 * a * rng.uniform(-0.5, 0.5, (N, 3))) % L
+    q = rng.normal(size=(N, 4)); q /= np.linalg.norm(q, axis=1)[:, None]
+    ps = inp.PhaseSpace(comps, np.array([L, L, L]), np.arange(1, N + 1, dtype=np.uint64), np.zeros(N, np.int32), r,
+                        np.zeros((N, 3)), q, np.zeros((N, 3)))
+    st = sorted_phase_space(ps)
+    ref = Oracle(comps.flat(), rc).forces(st["r"], st["q"], st["cid"], ps.length, True)
+    out = run_forces(ps, st, rc, True, kernel=capi.FK_AUTO)
+    assert out["kernel_family"] == 1
+    for k in ("F", "M", "Vi"):
+        assert rel_max(out[k], ref[k]) < TOL, k
+    assert abs(out["upot"] - ref["upot"]) <= TOL * abs(ref["upot"])
+    assert abs(out["virial"] - ref["virial"]) <= TOL * abs(ref["virial"])
+    cont = out["container"]
+    dom = mirror.Domain(ps.length)
+    cp = mirror.VectorizedCellProcessor(dom, rc, rc)
+    cont.traversePartialInnermostCells(cp, 0, 1)
+    cont.traverseNonInnermostCells(cp)
+    mol = cont.molecules()
+    o = np.argsort(mol["ids"])
+    frc = cont.forces()
+    assert np.array_equal(frc["F"][o], out["F"]) and np.array_equal(frc["M"][o], out["M"])

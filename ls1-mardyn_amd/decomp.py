@@ -144,6 +144,15 @@ class HaloExchanger:
         if not self.stage and decomp.world > 1 and os.environ.get("LS1_COUNTS_TRANSPORT", "nccl") == "gloo":
             self.meta_group = dist.new_group(backend="gloo")
 
+    def _self_p2p_ok(self):
+        """RCCL accepts grouped send/recv to the own rank (the loopback rehearsal relies on it); gloo does not."""
+        if self.stage:
+            return False
+        try:
+            return self.dist.get_backend(self.group) == "nccl"
+        except Exception:
+            return False
+
     def _side_stream(self):
         torch = self._torch
         if self._comm_stream is None:
@@ -192,6 +201,8 @@ class HaloExchanger:
         tot_out, tot_in = sum(n_out.values()), sum(n_in.values())
         ops = []
         sbuf = rbuf = None
+        self_copies = []  # (send view, peer) of loopback messages when the transport cannot send to the own rank (gloo)
+        self_p2p = self._self_p2p_ok()
         if tot_out:
             sbuf = torch.empty(tot_out * w, dtype=torch.float64, device=self.device)
             order = [d for p in self.peers for d in self._outgoing[p] if counts[d]]
@@ -202,14 +213,23 @@ class HaloExchanger:
             off = 0
             for p in self.peers:
                 if n_out[p]:
-                    ops.append(dist.P2POp(dist.isend, sbuf[off * w:(off + n_out[p]) * w], self.dc.real_rank(p), group=self.group))
+                    view = sbuf[off * w:(off + n_out[p]) * w]
+                    if self.dc.real_rank(p) == self.dc.rank and not self_p2p:
+                        self_copies.append((view, p))
+                    else:
+                        ops.append(dist.P2POp(dist.isend, view, self.dc.real_rank(p), group=self.group))
                     off += n_out[p]
         if tot_in:
             rbuf = torch.empty(tot_in * w, dtype=torch.float64, device="cpu" if self.stage else self.device)
             off = 0
             for p in self.peers:
                 if n_in[p]:
-                    ops.append(dist.P2POp(dist.irecv, rbuf[off * w:(off + n_in[p]) * w], self.dc.real_rank(p), group=self.group))
+                    view = rbuf[off * w:(off + n_in[p]) * w]
+                    if self.dc.real_rank(p) == self.dc.rank and not self_p2p:
+                        src = [v_ for v_, q_ in self_copies if q_ == p]
+                        view.copy_(src[0])
+                    else:
+                        ops.append(dist.P2POp(dist.irecv, view, self.dc.real_rank(p), group=self.group))
                     off += n_in[p]
         # The transfers are issued from a dedicated side stream: RCCL orders its kernels after an event on the CURRENT
         # torch stream, and the default (null) stream shares its hardware queue with the engine's main stream — the

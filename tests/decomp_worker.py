@@ -22,7 +22,7 @@ def main():
     from cpu_engine import CpuEngine
     data = np.load(os.environ["LS1_TEST_INPUT"])
     L, r, v, ids, rc = data["L"], data["r"], data["v"], data["ids"], float(data["rc"])
-    dc = decomp.CartesianDecomposition(world, rank, L, grid)
+    dc = decomp.CartesianDecomposition(world, rank, L, grid, loopback=bool(int(os.environ.get("LS1_TEST_LOOPBACK", "0"))))
     lo, hi = dc.bounding_box()
     mine = np.all((r >= lo) & (r < hi), axis=1)
     eng = CpuEngine(L, lo, hi, rank, dc.neighbor_table(), rc)

@@ -70,8 +70,13 @@ def _liquid(n, seed=5, rho=0.6, rc=2.5):
     return np.array([L] * 3), r, v
 
 
-@pytest.mark.parametrize("world,grid", [(2, "2x1x1"), (4, "2x2x1"), (2, "1x1x2")])
+@pytest.mark.parametrize("world,grid", [(2, "2x1x1"), (4, "2x2x1"), (2, "1x1x2"), (1, "1x1x1+loopback"),
+                                        (2, "2x1x1+loopback")])
 def test_gloo_world_matches_single_domain_oracle(world, grid):
+    """'+loopback': the periodic images a rank would create locally travel through the transport instead (messages to
+    the own rank), the rehearsal mode of bench.py --decomp --loopback."""
+    loopback = grid.endswith("+loopback")
+    grid = grid.split("+")[0]
     L, r, v = _liquid(5)  # 250 atoms, L ~ 7.5 (>= 2 rc per sub-box edge is NOT required: images handle it)
     rc, dt, nsteps = 1.8, 0.004, 4
     ids = np.arange(1, len(r) + 1, dtype=np.uint64)
@@ -87,9 +92,10 @@ def test_gloo_world_matches_single_domain_oracle(world, grid):
         inp_path = os.path.join(td, "in.npz")
         np.savez(inp_path, L=L, r=r, v=v, ids=ids, rc=rc)
         out_path = os.path.join(td, "out.npz")
-        env = dict(os.environ, LS1_TEST_INPUT=inp_path, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+        env = dict(os.environ, LS1_TEST_INPUT=inp_path, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1",
+                   LS1_TEST_LOOPBACK="1" if loopback else "0")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-               "--master-addr", "127.0.0.1", "--master-port", str(29500 + world + (7 if grid == "1x1x2" else 0)),
+               "--master-addr", "127.0.0.1", "--master-port", str(29500 + world + (7 if grid == "1x1x2" else 0) + (20 if loopback else 0)),
                os.path.join(ROOT, "tests", "decomp_worker.py"), out_path, str(nsteps), repr(dt), grid]
         res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]

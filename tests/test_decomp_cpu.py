@@ -57,6 +57,13 @@ def test_neighbor_table_2x2x2_has_seven_peers():
     assert open_dc.neighbor_table()[12] == -1 and open_dc.neighbor_table()[14] == 1
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _liquid(n, seed=5, rho=0.6, rc=2.5):
     rng = np.random.default_rng(seed)
     N = 2 * n ** 3
@@ -95,7 +102,7 @@ def test_gloo_world_matches_single_domain_oracle(world, grid):
         env = dict(os.environ, LS1_TEST_INPUT=inp_path, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1",
                    LS1_TEST_LOOPBACK="1" if loopback else "0")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-               "--master-addr", "127.0.0.1", "--master-port", str(29500 + world + (7 if grid == "1x1x2" else 0) + (20 if loopback else 0)),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                os.path.join(ROOT, "tests", "decomp_worker.py"), out_path, str(nsteps), repr(dt), grid]
         res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]

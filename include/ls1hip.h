@@ -242,7 +242,8 @@ int ls1hip_soa_forces(ls1hip_ctx* ctx, const int cell_dims[3], const uint32_t* c
  * since the last reset: names[] in {"force","integrate","rebin","halo"}. */
 int ls1hip_timing(ls1hip_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);
 int ls1hip_timing_reset(ls1hip_ctx* ctx);
-/* Enable (1) / disable (0) per-launch HIP-event timing (adds a little host overhead). */
+/* Per-launch HIP-event timing: 0 = off, 1 = every phase, 2 = force passes only (each timed scope puts two event markers
+ * into the stream, ~10 us of device idle per scope: a measured run that needs the force-kernel duration only uses 2). */
 int ls1hip_timing_enable(ls1hip_ctx* ctx, int on);
 /* Pair statistics of the last force call: distance checks and in-range molecule pairs (as FlopCounter counts
  * them, adapter/FlopCounter.cpp:20-76); requires option "count_pairs"=1. */

@@ -38,7 +38,7 @@ struct TimedScope {
 	hipEvent_t stop = nullptr;
 	hipStream_t s;
 	TimedScope(ls1hip_ctx* ctx, Timer& tm, hipStream_t stream = nullptr) : c(ctx), t(&tm), s(stream ? stream : ctx->stream) {
-		if (!c->timing_on) return;
+		if (!c->timing_on || (c->timing_on == 2 && t != &c->t_force)) return;
 		if (t->used + 2 > t->ev.size()) {
 			hipEvent_t a, b;
 			if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
@@ -750,7 +750,10 @@ static int launch_forces(ls1hip_ctx* c, int which, bool fuse = false, double dt 
 		P.vx = m.vx; P.vy = m.vy; P.vz = m.vz;
 	}
 	uint32_t nblocks = 0;
-	if (which == 0 || which == 1) launch_clear_macro(c->d_cnt, c->stream);
+	// the first pass of a traversal starts the macroscopic sums: the reduction overwrites them (pair counting, a
+	// diagnostic mode, also needs its counters cleared before the kernel)
+	const bool first_pass = which == 0 || which == 1;
+	if (first_pass && c->opt_count_pairs) launch_clear_macro(c->d_cnt, c->stream);
 	bool done = false;
 	const double ncell = (double)c->g.box[0] * c->g.box[1] * c->g.box[2];
 	const double mean_per_cell = ncell > 0 ? (double)c->n_real / ncell : 0.;
@@ -769,7 +772,7 @@ static int launch_forces(ls1hip_ctx* c, int which, bool fuse = false, double dt 
 		const double nbrs = vol > 0. ? (double)c->n_real / vol * 4.18879 * c->rc * c->rc * c->rc : 0.;
 		launch_force_generic(P, c->one_clj, c->opt_vi != 0, c->h_ct.has_rot != 0, c->stream, &nblocks, nbrs);
 	}
-	launch_force_reduce(c->d_cnt, c->d_partials, nblocks, c->d_stage, c->stream);
+	launch_force_reduce(c->d_cnt, c->d_partials, nblocks, c->d_stage, c->stream, first_pass && !c->opt_count_pairs);
 	HIPCHK(c, hipGetLastError());
 	return LS1HIP_OK;
 }
@@ -1286,7 +1289,8 @@ extern "C" int ls1hip_timing_reset(ls1hip_ctx* c) {
 
 extern "C" int ls1hip_timing_enable(ls1hip_ctx* c, int on) {
 	if (!c) return LS1HIP_EINVAL;
-	c->timing_on = on != 0;
+	REQUIRE(c, on >= 0 && on <= 2, "timing mode must be 0 (off), 1 (all phases) or 2 (force passes only)");
+	c->timing_on = on;
 	return LS1HIP_OK;
 }
 

@@ -156,7 +156,7 @@ struct ls1hip_ctx {
 	bool thermostat_on = false;
 	double thermostat_T = 0.;
 	// timing
-	bool timing_on = false;
+	int timing_on = 0;  // 0 off, 1 all phases, 2 force passes only
 	ls1::Timer t_force, t_integrate, t_rebin, t_halo;
 	std::vector<void*> allocs;
 };
@@ -222,7 +222,8 @@ bool launch_force_lj(const ForceParams& p, hipStream_t s, uint32_t* nblocks, dou
 // brick-tiled multi-site kernel (kernels_force_ms.hip); returns false if it cannot handle the configuration
 bool launch_force_ms(const ForceParams& p, bool with_vi, bool has_rot, hipStream_t s, uint32_t* nblocks, size_t partials_cap,
 					 double mean_per_cell, BrickLists* bl);
-void launch_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, double* stage, hipStream_t s);
+void launch_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, double* stage, hipStream_t s,
+						 bool overwrite = false);
 void launch_clear_macro(DevCounters* cnt, hipStream_t s);
 
 struct IntegArgs {

@@ -268,6 +268,13 @@ void launch_force_generic(const ForceParams& p, bool one_clj, bool with_vi, bool
 	}
 }
 
+__global__ void k_clear_macro(DevCounters* cnt) {
+	for (int k = 0; k < 4; ++k) cnt->macro[k] = 0.;
+	cnt->dist_checks = 0;
+	cnt->pairs_in_range = 0;
+}
+void launch_clear_macro(DevCounters* cnt, hipStream_t s) { hipLaunchKernelGGL(k_clear_macro, dim3(1), dim3(1), 0, s, cnt); }
+
 // deterministic reduction of the per-workgroup partials in two fixed-shape stages (RED_BLOCKS x 256 threads, then one
 // block), ADDED to cnt->macro; the summation order depends only on the number of partials, never on timing.
 constexpr int RED_BLOCKS = 128;
@@ -283,7 +290,7 @@ __global__ void __launch_bounds__(256) k_force_reduce1(const double* partials, u
 	__syncthreads();
 	if (threadIdx.x < 4) stage[blockIdx.x * 4 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
-__global__ void __launch_bounds__(RED_BLOCKS) k_force_reduce2(DevCounters* cnt, const double* stage) {
+__global__ void __launch_bounds__(RED_BLOCKS) k_force_reduce2(DevCounters* cnt, const double* stage, int overwrite) {
 	double v[4];
 	for (int k = 0; k < 4; ++k) v[k] = stage[threadIdx.x * 4 + k];
 	__shared__ double red[RED_BLOCKS / 64][4];
@@ -295,21 +302,17 @@ __global__ void __launch_bounds__(RED_BLOCKS) k_force_reduce2(DevCounters* cnt, 
 	if (threadIdx.x < 4) {
 		double s = 0.;
 		for (int i = 0; i < RED_BLOCKS / 64; ++i) s += red[i][threadIdx.x];
-		cnt->macro[threadIdx.x] += s;
+		cnt->macro[threadIdx.x] = overwrite ? s : cnt->macro[threadIdx.x] + s;  // first pass of a traversal starts the sums
 	}
 }
 
-void launch_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, double* stage, hipStream_t s) {
-	if (nblocks == 0) return;
+void launch_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, double* stage, hipStream_t s, bool overwrite) {
+	if (nblocks == 0) {
+		if (overwrite) launch_clear_macro(cnt, s);
+		return;
+	}
 	hipLaunchKernelGGL(k_force_reduce1, dim3(RED_BLOCKS), dim3(256), 0, s, partials, nblocks, stage);
-	hipLaunchKernelGGL(k_force_reduce2, dim3(1), dim3(RED_BLOCKS), 0, s, cnt, stage);
+	hipLaunchKernelGGL(k_force_reduce2, dim3(1), dim3(RED_BLOCKS), 0, s, cnt, stage, overwrite ? 1 : 0);
 }
-
-__global__ void k_clear_macro(DevCounters* cnt) {
-	for (int k = 0; k < 4; ++k) cnt->macro[k] = 0.;
-	cnt->dist_checks = 0;
-	cnt->pairs_in_range = 0;
-}
-void launch_clear_macro(DevCounters* cnt, hipStream_t s) { hipLaunchKernelGGL(k_clear_macro, dim3(1), dim3(1), 0, s, cnt); }
 
 }  // namespace ls1

@@ -168,10 +168,14 @@ __global__ void __launch_bounds__(TPB) k_scan_blocksums(Grid g, const uint32_t* 
 	if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
 }
 
-__global__ void __launch_bounds__(TPB) k_scan_top(uint32_t* blocksum, int nblocks, DevCounters* cnt, int mode) {
+__global__ void __launch_bounds__(TPB) k_scan_top(uint32_t* blocksum, int nblocks, DevCounters* cnt, int mode, uint32_t cap_halo) {
 	// single block: exclusive scan of the block sums in chunks of TPB
 	__shared__ uint32_t carry;
-	if (threadIdx.x == 0) carry = (mode == 1) ? cnt->n_real : 0u;
+	if (threadIdx.x == 0) {
+		carry = (mode == 1) ? cnt->n_real : 0u;
+		// halo pass: clamp the staged count to the capacity (after an overflow the error flag is set; keeps indices in range)
+		if (mode == 1 && cnt->n_halo_staged > cap_halo) cnt->n_halo_staged = cap_halo;
+	}
 	__syncthreads();
 	for (int base = 0; base < nblocks; base += TPB) {
 		const int i = base + threadIdx.x;
@@ -215,10 +219,10 @@ __global__ void __launch_bounds__(TPB) k_scan_apply(Grid g, const uint32_t* coun
 }
 
 static void run_scan(const Grid& g, const uint32_t* count, uint32_t* blocksum, uint32_t* cell_begin, uint32_t* cell_end,
-					 DevCounters* cnt, int mode, hipStream_t s) {
+					 DevCounters* cnt, int mode, hipStream_t s, uint32_t cap_halo = 0) {
 	const int nblocks = (g.ncells + SCAN_BLOCK - 1) / SCAN_BLOCK;
 	hipLaunchKernelGGL(k_scan_blocksums, dim3(nblocks), dim3(TPB), 0, s, g, count, blocksum, mode);
-	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(TPB), 0, s, blocksum, nblocks, cnt, mode);
+	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(TPB), 0, s, blocksum, nblocks, cnt, mode, cap_halo);
 	hipLaunchKernelGGL(k_scan_apply, dim3(nblocks), dim3(TPB), 0, s, g, count, blocksum, cell_begin, cell_end, mode);
 }
 
@@ -297,9 +301,15 @@ __global__ void __launch_bounds__(TPB) k_gather(RebinArgs a) {
 	}
 }
 
+// cell counters and leaving-export counters of a new re-bin (one launch; two hipMemsetAsync were four fill kernels)
+__global__ void __launch_bounds__(TPB) k_rebin_reset(uint32_t* count, int ncells, DevCounters* cnt) {
+	const int c = blockIdx.x * TPB + threadIdx.x;
+	if (c < ncells) count[c] = 0;
+	if (c < 27) cnt->exp_leave[c] = 0;
+}
+
 void launch_rebin_classify(const RebinArgs& a, hipStream_t s) {
-	hipMemsetAsync(a.count, 0, sizeof(uint32_t) * (size_t)a.g.ncells, s);
-	hipMemsetAsync(&a.cnt->exp_leave[0], 0, sizeof(uint32_t) * 27, s);
+	hipLaunchKernelGGL(k_rebin_reset, dim3((a.g.ncells + TPB - 1) / TPB), dim3(TPB), 0, s, a.count, a.g.ncells, a.cnt);
 	if (a.n_in == 0) return;
 	hipLaunchKernelGGL(k_classify, dim3((a.n_in + TPB - 1) / TPB), dim3(TPB), 0, s, a);
 }
@@ -582,15 +592,14 @@ __global__ void __launch_bounds__(TPB) k_halo_gather(HaloArgs a) {
 	}
 }
 
-__global__ void k_halo_reset(DevCounters* cnt) {
-	cnt->n_halo = 0;
-	cnt->n_halo_staged = 0;
-	for (int i = 0; i < 27; ++i) cnt->exp_halo[i] = 0;
-}
-
 // zero the per-cell counters of halo cells only (real cells keep their counts from the rebin)
-__global__ void __launch_bounds__(TPB) k_zero_halo_counts(Grid g, uint32_t* count) {
+__global__ void __launch_bounds__(TPB) k_zero_halo_counts(Grid g, uint32_t* count, DevCounters* cnt) {
 	const int c = blockIdx.x * TPB + threadIdx.x;
+	if (c == 0) {  // the halo counters of the new exchange (was a separate one-thread launch)
+		cnt->n_halo = 0;
+		cnt->n_halo_staged = 0;
+	}
+	if (c < 27) cnt->exp_halo[c] = 0;
 	if (c >= g.ncells) return;
 	int cx, cy, cz;
 	cell_coords(g, c, cx, cy, cz);
@@ -598,8 +607,7 @@ __global__ void __launch_bounds__(TPB) k_zero_halo_counts(Grid g, uint32_t* coun
 }
 
 void launch_halo_generate(const HaloArgs& a, hipStream_t s) {
-	hipLaunchKernelGGL(k_halo_reset, dim3(1), dim3(1), 0, s, a.cnt);
-	hipLaunchKernelGGL(k_zero_halo_counts, dim3((a.g.ncells + TPB - 1) / TPB), dim3(TPB), 0, s, a.g, a.count);
+	hipLaunchKernelGGL(k_zero_halo_counts, dim3((a.g.ncells + TPB - 1) / TPB), dim3(TPB), 0, s, a.g, a.count, a.cnt);
 	if (a.n_real_cap == 0) return;
 	if (a.nshell == 0) return;
 	hipLaunchKernelGGL(k_halo_gen, dim3(((size_t)a.nshell * HG_LANES + TPB * HG_ITER - 1) / (TPB * HG_ITER)), dim3(TPB), 0, s, a);
@@ -608,11 +616,6 @@ void launch_halo_generate(const HaloArgs& a, hipStream_t s) {
 void launch_halo_import(const HaloArgs& a, const double* dev_records, uint32_t n, hipStream_t s) {
 	if (n == 0) return;
 	hipLaunchKernelGGL(k_halo_import, dim3((n + HI_TPB - 1) / HI_TPB), dim3(HI_TPB), 0, s, a, dev_records, n);
-}
-
-// clamp n_halo to the capacity (after an overflow the error flag is set; keep indices in range)
-__global__ void k_halo_clamp(DevCounters* cnt, uint32_t cap) {
-	if (cnt->n_halo_staged > cap) cnt->n_halo_staged = cap;
 }
 
 __global__ void __launch_bounds__(TPB) k_halo_scatter(HaloArgs a) {
@@ -624,8 +627,7 @@ __global__ void __launch_bounds__(TPB) k_halo_scatter(HaloArgs a) {
 }
 
 void launch_halo_finalize(const HaloArgs& a, hipStream_t s) {
-	hipLaunchKernelGGL(k_halo_clamp, dim3(1), dim3(1), 0, s, a.cnt, a.cap_halo);
-	run_scan(a.g, a.count, a.blocksum, a.cell_begin, a.cell_end, a.cnt, 1, s);
+	run_scan(a.g, a.count, a.blocksum, a.cell_begin, a.cell_end, a.cnt, 1, s, a.cap_halo);
 	if (a.cap_halo == 0) return;
 	const dim3 grid((a.cap_halo + TPB - 1) / TPB);
 	hipLaunchKernelGGL(k_halo_scatter, grid, dim3(TPB), 0, s, a);

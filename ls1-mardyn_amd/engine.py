@@ -213,8 +213,9 @@ class DeviceEngine:
         return dict(F=F, M=M, Vi=Vi, upot=u.value, virial=w.value)
 
     # -- measurement ------------------------------------------------------------------------------------------------
-    def timing_enable(self, on: bool):
-        self._chk(self.lib.ls1hip_timing_enable(self.ctx, int(bool(on))))
+    def timing_enable(self, on):
+        """0 / False = off, 1 / True = every phase, 2 = force passes only"""
+        self._chk(self.lib.ls1hip_timing_enable(self.ctx, int(on)))
 
     def timing_reset(self):
         self._chk(self.lib.ls1hip_timing_reset(self.ctx))

@@ -168,34 +168,21 @@ __global__ void __launch_bounds__(TPB) k_scan_blocksums(Grid g, const uint32_t* 
 	if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
 }
 
-__global__ void __launch_bounds__(TPB) k_scan_top(uint32_t* blocksum, int nblocks, DevCounters* cnt, int mode, uint32_t cap_halo) {
-	// single block: exclusive scan of the block sums in chunks of TPB
-	__shared__ uint32_t carry;
-	if (threadIdx.x == 0) {
-		carry = (mode == 1) ? cnt->n_real : 0u;
-		// halo pass: clamp the staged count to the capacity (after an overflow the error flag is set; keeps indices in range)
-		if (mode == 1 && cnt->n_halo_staged > cap_halo) cnt->n_halo_staged = cap_halo;
-	}
-	__syncthreads();
-	for (int base = 0; base < nblocks; base += TPB) {
-		const int i = base + threadIdx.x;
-		const uint32_t v = (i < nblocks) ? blocksum[i] : 0u;
+// Second and last pass of the scan: every block sums the block sums in front of it (a few hundred values: cheaper than
+// a separate single-block "top" launch), scans its own cells and writes cell_begin / cell_end; the last block publishes
+// the total (n_real or n_halo).
+__global__ void __launch_bounds__(TPB) k_scan_apply(Grid g, const uint32_t* count, const uint32_t* blocksum, int nblocks,
+													uint32_t* cell_begin, uint32_t* cell_end, DevCounters* cnt, int mode,
+													uint32_t cap_halo) {
+	__shared__ uint32_t s_base;
+	{
+		uint32_t part = 0;
+		for (int i = threadIdx.x; i < (int)blockIdx.x; i += TPB) part += blocksum[i];
 		uint32_t tot;
-		const uint32_t ex = block_exclusive_scan(v, &tot);
-		const uint32_t c = carry;
-		if (i < nblocks) blocksum[i] = c + ex;
-		__syncthreads();
-		if (threadIdx.x == 0) carry = c + tot;
+		block_exclusive_scan(part, &tot);
+		if (threadIdx.x == 0) s_base = tot + ((mode == 1) ? cnt->n_real : 0u);
 		__syncthreads();
 	}
-	if (threadIdx.x == 0) {
-		if (mode == 0) cnt->n_real = carry;
-		else cnt->n_halo = carry - cnt->n_real;
-	}
-}
-
-__global__ void __launch_bounds__(TPB) k_scan_apply(Grid g, const uint32_t* count, const uint32_t* blocksum,
-													uint32_t* cell_begin, uint32_t* cell_end, int mode) {
 	const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
 	uint32_t vals[SCAN_ITEMS], v = 0;
 	for (int i = 0; i < SCAN_ITEMS; ++i) {
@@ -203,7 +190,7 @@ __global__ void __launch_bounds__(TPB) k_scan_apply(Grid g, const uint32_t* coun
 		v += vals[i];
 	}
 	uint32_t tot;
-	uint32_t ex = block_exclusive_scan(v, &tot) + blocksum[blockIdx.x];
+	uint32_t ex = block_exclusive_scan(v, &tot) + s_base;
 	for (int i = 0; i < SCAN_ITEMS; ++i) {
 		const int c = base + i;
 		if (c < g.ncells) {
@@ -216,14 +203,24 @@ __global__ void __launch_bounds__(TPB) k_scan_apply(Grid g, const uint32_t* coun
 		}
 		ex += vals[i];
 	}
+	if ((int)blockIdx.x == nblocks - 1 && threadIdx.x == 0) {
+		const uint32_t total = s_base + tot;
+		if (mode == 0) {
+			cnt->n_real = total;
+		} else {
+			cnt->n_halo = total - cnt->n_real;
+			// clamp the staged count to the capacity (after an overflow the error flag is set; keeps indices in range)
+			if (cnt->n_halo_staged > cap_halo) cnt->n_halo_staged = cap_halo;
+		}
+	}
 }
 
 static void run_scan(const Grid& g, const uint32_t* count, uint32_t* blocksum, uint32_t* cell_begin, uint32_t* cell_end,
 					 DevCounters* cnt, int mode, hipStream_t s, uint32_t cap_halo = 0) {
 	const int nblocks = (g.ncells + SCAN_BLOCK - 1) / SCAN_BLOCK;
 	hipLaunchKernelGGL(k_scan_blocksums, dim3(nblocks), dim3(TPB), 0, s, g, count, blocksum, mode);
-	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(TPB), 0, s, blocksum, nblocks, cnt, mode, cap_halo);
-	hipLaunchKernelGGL(k_scan_apply, dim3(nblocks), dim3(TPB), 0, s, g, count, blocksum, cell_begin, cell_end, mode);
+	hipLaunchKernelGGL(k_scan_apply, dim3(nblocks), dim3(TPB), 0, s, g, count, blocksum, nblocks, cell_begin, cell_end, cnt, mode,
+					   cap_halo);
 }
 
 // ---- stage B: scatter -> canonical in-cell order -> gather ------------------------------------------------------

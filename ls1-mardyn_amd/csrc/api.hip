@@ -482,7 +482,7 @@ static int alloc_mol(ls1hip_ctx* c, size_t n) {
 	if (rc) return rc;
 	(rc = dalloc(c, &c->d_key, cap_real)) || (rc = dalloc(c, &c->d_rank, cap_real)) ||
 		(rc = dalloc(c, &c->d_perm, std::max(cap_real, cap_halo))) || (rc = dalloc(c, &c->d_ckey, cap_real)) ||
-		(rc = dalloc(c, &c->d_idk, cap_real));
+		(rc = dalloc(c, &c->d_idk, std::max(cap_real, cap_halo)));
 	if (rc) return rc;
 	c->partials_cap = partials_cap;
 	if ((rc = dalloc(c, &c->d_partials, c->partials_cap * 4))) return rc;
@@ -649,6 +649,7 @@ static HaloArgs halo_args(ls1hip_ctx* c) {
 	a.has_rot = c->h_ct.has_rot;
 	a.perm = c->d_perm; a.count = c->d_count; a.cell_begin = c->d_cell_begin; a.cell_end = c->d_cell_end;
 	a.blocksum = c->d_blocksum;
+	a.idk = c->d_idk;
 	a.shell = c->d_shell;
 	a.nshell = c->n_shell;
 	a.cnt = c->d_cnt;

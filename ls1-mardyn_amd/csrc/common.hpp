@@ -189,6 +189,7 @@ struct HaloArgs {
 	HaloStage hs;
 	bool has_rot;
 	uint32_t *perm, *count, *cell_begin, *cell_end, *blocksum;
+	uint64_t* idk;  // ids of the staged halo copies in slot order (canonical in-cell order by counting, as in k_gather)
 	const uint32_t* shell;  // owned cells within 2*hw of a face (the only ones that can feed the halo)
 	uint32_t nshell;
 	DevCounters* cnt;

@@ -235,30 +235,6 @@ __global__ void __launch_bounds__(TPB) k_scatter(const uint32_t* key, const uint
 	if (idk) idk[slot] = id[p];  // ids in slot order: the canonical-order pass reads them contiguously per cell
 }
 
-// one thread per cell: insertion sort of the cell's slice of `perm` by molecule id (cells hold ~12 molecules)
-__global__ void __launch_bounds__(TPB) k_cellsort(Grid g, const uint32_t* cell_begin, const uint32_t* cell_end,
-												  uint32_t* perm, const uint64_t* id, const DevCounters* cnt, int mode) {
-	const int c = blockIdx.x * TPB + threadIdx.x;
-	if (c >= g.ncells) return;
-	int cx, cy, cz;
-	cell_coords(g, c, cx, cy, cz);
-	if (cell_is_halo(g, cx, cy, cz) != (mode == 1)) return;
-	const uint32_t sub = (mode == 1) ? cnt->n_real : 0u;
-	const uint32_t b = cell_begin[c] - sub, e = cell_end[c] - sub;
-	for (uint32_t i = b + 1; i < e; ++i) {
-		const uint32_t pi = perm[i];
-		const uint64_t idi = id[pi];
-		uint32_t j = i;
-		while (j > b) {
-			const uint32_t pj = perm[j - 1];
-			if (id[pj] <= idi) break;
-			perm[j] = pj;
-			--j;
-		}
-		perm[j] = pi;
-	}
-}
-
 // Gather into the new set.  Slot k (arrival order inside its cell) is moved to its canonical position: the cell's
 // molecules ordered by id, found by counting the smaller ids in the cell's slice (a dozen contiguous, L1-resident
 // u64) — no serial per-cell sort, every thread stays busy.
@@ -575,7 +551,21 @@ __global__ void __launch_bounds__(TPB) k_halo_gather(HaloArgs a) {
 	const uint32_t k = blockIdx.x * TPB + threadIdx.x;
 	if (k >= a.cnt->n_halo) return;
 	const uint32_t i = a.perm[k];
-	const uint32_t p = a.cnt->n_real + k;
+	const uint32_t n_real = a.cnt->n_real;
+	uint32_t p = n_real + k;
+	if (a.deterministic) {
+		// canonical position inside the halo cell: its copies ordered by molecule id, by counting the smaller ids of the
+		// cell's slice (as k_gather does for the owned cells; replaces a serial per-cell insertion sort pass)
+		const uint32_t key = a.hs.key[i];
+		const uint32_t cb = a.cell_begin[key] - n_real, ce = a.cell_end[key] - n_real;
+		const uint64_t myid = a.idk[k];
+		uint32_t r = 0;
+		for (uint32_t q = cb; q < ce; ++q) {
+			const uint64_t o = a.idk[q];
+			r += (o < myid) || (o == myid && q < k);
+		}
+		p = n_real + cb + r;
+	}
 	a.mol.x[p] = a.hs.x[i];
 	a.mol.y[p] = a.hs.y[i];
 	a.mol.z[p] = a.hs.z[i];
@@ -620,7 +610,9 @@ __global__ void __launch_bounds__(TPB) k_halo_scatter(HaloArgs a) {
 	if (i >= a.cnt->n_halo_staged) return;
 	const uint32_t k = a.hs.key[i];
 	if (k == KEY_INVALID) return;
-	a.perm[a.cell_begin[k] + a.hs.rank[i] - a.cnt->n_real] = i;
+	const uint32_t slot = a.cell_begin[k] + a.hs.rank[i] - a.cnt->n_real;
+	a.perm[slot] = i;
+	a.idk[slot] = a.hs.id[i];
 }
 
 void launch_halo_finalize(const HaloArgs& a, hipStream_t s) {
@@ -628,9 +620,6 @@ void launch_halo_finalize(const HaloArgs& a, hipStream_t s) {
 	if (a.cap_halo == 0) return;
 	const dim3 grid((a.cap_halo + TPB - 1) / TPB);
 	hipLaunchKernelGGL(k_halo_scatter, grid, dim3(TPB), 0, s, a);
-	if (a.deterministic)
-		hipLaunchKernelGGL(k_cellsort, dim3((a.g.ncells + TPB - 1) / TPB), dim3(TPB), 0, s, a.g, a.cell_begin, a.cell_end,
-						   a.perm, a.hs.id, a.cnt, 1);
 	hipLaunchKernelGGL(k_halo_gather, grid, dim3(TPB), 0, s, a);
 }
 

@@ -33,7 +33,7 @@ FORCE_BYTES_PER_MOLECULE = 48.0   # read r (24 B) + write F (24 B): SURVEY.md 8(
 # fused force + integration pass (between steps, reduced-memory mode): read r, v (48 B) + write r', v' (48 B); F never
 # reaches HBM and the 120 B integrator pass disappears (SURVEY.md 8(d) force 48 B + integrator 120 B -> 96 B)
 FUSED_BYTES_PER_MOLECULE = 96.0
-PMC_SUMMARY = "r1_f_pmc_summary.json"  # rocprofv3 PMC passes of this workload (tools/collect_profiles.sh)
+PMC_SUMMARY = "r1_g_pmc_summary.json"  # rocprofv3 PMC passes of this workload (tools/collect_profiles.sh)
 STEP_BYTES_PER_MOLECULE = 292.0   # full step: force 48 + integrator 120 + re-bin 124
 HBM_PEAK_GBS = 8000.0
 

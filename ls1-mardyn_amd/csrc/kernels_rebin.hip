@@ -235,6 +235,24 @@ __global__ void __launch_bounds__(TPB) k_scatter(const uint32_t* key, const uint
 	if (idk) idk[slot] = id[p];  // ids in slot order: the canonical-order pass reads them contiguously per cell
 }
 
+// Number of entries of idk[cb, ce) that precede (myid, k) in (id, slot) order.  Eight loads are issued per trip before any
+// is used: with one load per trip the loop was a chain of ~12 L1 latencies per molecule (0.1 ms of the re-bin).
+__device__ __forceinline__ uint32_t rank_by_id(const uint64_t* idk, uint32_t cb, uint32_t ce, uint32_t k, uint64_t myid) {
+	uint32_t r = 0;
+	constexpr int U = 8;  // 16 measured slower (0.43 vs 0.41 ms re-bin): wasted loads on 12-molecule cells
+	for (uint32_t q0 = cb; q0 < ce; q0 += U) {
+		uint64_t o[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u) o[u] = idk[min(q0 + (uint32_t)u, ce - 1u)];
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const uint32_t q = q0 + (uint32_t)u;
+			r += (q < ce) & ((o[u] < myid) | ((o[u] == myid) & (q < k)));
+		}
+	}
+	return r;
+}
+
 // Gather into the new set.  Slot k (arrival order inside its cell) is moved to its canonical position: the cell's
 // molecules ordered by id, found by counting the smaller ids in the cell's slice (a dozen contiguous, L1-resident
 // u64) — no serial per-cell sort, every thread stays busy.
@@ -247,12 +265,7 @@ __global__ void __launch_bounds__(TPB) k_gather(RebinArgs a) {
 	if (a.deterministic) {
 		const uint32_t cb = a.cell_begin[key], ce = a.cell_end[key];
 		const uint64_t myid = a.idk[k];
-		uint32_t r = 0;
-		for (uint32_t q = cb; q < ce; ++q) {
-			const uint64_t o = a.idk[q];
-			r += (o < myid) || (o == myid && q < k);
-		}
-		p = cb + r;
+		p = cb + rank_by_id(a.idk, cb, ce, k, myid);
 	}
 	a.dst.x[p] = a.src.x[i];
 	a.dst.y[p] = a.src.y[i];
@@ -561,12 +574,7 @@ __global__ void __launch_bounds__(TPB) k_halo_gather(HaloArgs a) {
 		const uint32_t key = a.hs.key[i];
 		const uint32_t cb = a.cell_begin[key] - n_real, ce = a.cell_end[key] - n_real;
 		const uint64_t myid = a.idk[k];
-		uint32_t r = 0;
-		for (uint32_t q = cb; q < ce; ++q) {
-			const uint64_t o = a.idk[q];
-			r += (o < myid) || (o == myid && q < k);
-		}
-		p = n_real + cb + r;
+		p = n_real + cb + rank_by_id(a.idk, cb, ce, k, myid);
 	}
 	a.mol.x[p] = a.hs.x[i];
 	a.mol.y[p] = a.hs.y[i];

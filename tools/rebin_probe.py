@@ -1,0 +1,23 @@
+"""Times the re-bin phase of the bench workload with the canonical (by id) in-cell order on / off."""
+import importlib, sys, os
+import numpy as np
+sys.path.insert(0, os.getcwd())
+import bench
+inp = importlib.import_module("ls1-mardyn_amd.inp")
+engine_mod = importlib.import_module("ls1-mardyn_amd.engine")
+import torch
+L, r, v = bench.bcc_box(171)
+N = len(r)
+for det in (1, 0):
+    eng = engine_mod.DeviceEngine(0)
+    eng.set_components(bench.lj_components(inp), bench.RC)
+    eng.set_option("deterministic", det)
+    eng.set_domain([L, L, L])
+    eng.upload(np.arange(1, N + 1, dtype=np.uint64), np.zeros(N, np.int32), r, v)
+    eng.rebin(); eng.halo(); eng.forces(0)
+    eng.run(bench.DT, 5)
+    eng.timing_reset(); eng.timing_enable(1)
+    eng.run(bench.DT, 20)
+    torch.cuda.synchronize()
+    print("deterministic", det, {k: eng.timing(k)[0] / 20 for k in ("rebin", "halo", "force")})
+    eng.close()

@@ -260,6 +260,11 @@ __global__ void __launch_bounds__(TPB) k_gather(RebinArgs a) {
 	const uint32_t k = blockIdx.x * TPB + threadIdx.x;
 	if (k >= a.cnt->n_real) return;
 	const uint32_t i = a.perm[k];
+	// the payload loads depend on i only: issue them before the rank computation so that their latency overlaps it
+	const double x = a.src.x[i], y = a.src.y[i], z = a.src.z[i];
+	const double vx = a.src.vx[i], vy = a.src.vy[i], vz = a.src.vz[i];
+	const uint64_t id = a.src.id[i];
+	const int32_t cid = a.src.cid[i];
 	const uint32_t key = a.key[i];
 	uint32_t p = k;
 	if (a.deterministic) {
@@ -267,14 +272,14 @@ __global__ void __launch_bounds__(TPB) k_gather(RebinArgs a) {
 		const uint64_t myid = a.idk[k];
 		p = cb + rank_by_id(a.idk, cb, ce, k, myid);
 	}
-	a.dst.x[p] = a.src.x[i];
-	a.dst.y[p] = a.src.y[i];
-	a.dst.z[p] = a.src.z[i];
-	a.dst.vx[p] = a.src.vx[i];
-	a.dst.vy[p] = a.src.vy[i];
-	a.dst.vz[p] = a.src.vz[i];
-	a.dst.id[p] = a.src.id[i];
-	a.dst.cid[p] = a.src.cid[i];
+	a.dst.x[p] = x;
+	a.dst.y[p] = y;
+	a.dst.z[p] = z;
+	a.dst.vx[p] = vx;
+	a.dst.vy[p] = vy;
+	a.dst.vz[p] = vz;
+	a.dst.id[p] = id;
+	a.dst.cid[p] = cid;
 	a.ckey[p] = key;
 	if (a.has_rot) {
 		a.dst.q0[p] = a.src.q0[i];

@@ -3,6 +3,9 @@ import numpy as np
 sys.path.insert(0, os.getcwd())
 import bench
 inp = importlib.import_module("ls1-mardyn_amd.inp")
+capi = importlib.import_module("ls1-mardyn_amd.capi")
+if len(sys.argv) > 1:
+    capi.LIB_PATH = os.path.abspath(sys.argv[1])  # probe a library variant
 engine_mod = importlib.import_module("ls1-mardyn_amd.engine")
 import torch
 L, r, v = bench.bcc_box(171)

@@ -681,6 +681,11 @@ extern "C" int ls1hip_rebin(ls1hip_ctx* c) {
 	if (!c) return LS1HIP_EINVAL;
 	REQUIRE(c, c->have_domain && c->cap_real, "no molecules uploaded");
 	HIPCHK(c, hipSetDevice(c->device));
+	REQUIRE(c, !c->fused_split, "a fused inner pass (which=1) is waiting for its which=2 pass");
+	if (c->inner_in_flight) {  // an inner pass that was never completed by a boundary pass: leave the two-stream mode cleanly
+		HIPCHK(c, hipStreamSynchronize(c->stream2));
+		c->inner_in_flight = false;
+	}
 	TimedScope ts(c, c->t_rebin);
 	RebinArgs a = rebin_args(c, (uint32_t)c->n_real);
 	launch_rebin_classify(a, c->stream);

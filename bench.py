@@ -4,11 +4,14 @@
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
 
 A "step" is one full time step of the hot path (Leapfrog pre-force kick+drift -> re-bin -> halo -> pair forces ->
-post-force kick) over the synthetic liquid of BASELINE.json configs[1]: single-centre Lennard-Jones, rho*=0.785302672,
-rc=2.5 sigma, T*=0.95, dt=0.002, N = 2*171^3 = 10 000 422 per GPU (weak scaling), FP64.  Inputs are resident in HBM
-before the timed region.  Prints ONE JSON line (rank 0) with `roofline` (force kernel: algorithmic bytes / HIP-event
-kernel time vs 8 TB/s) and `cpu_baseline` (the REAL reference binary oracle/_ref/MarDyn timed on the host cores on a
-bounded sample of the same workload; the oracle restatement is used only if that binary is absent).
+post-force kick, with the per-step global values U_pot / virial / sum m v^2) over the synthetic liquid BASELINE.json's
+metric is quoted on: single-centre Lennard-Jones, rho*=0.785302672, rc=2.5 sigma, T*=0.95, dt=0.002, FP64,
+N = 2*368^3 = 99 672 064 (the "10^8" box), which fits ONE MI355X; `--gpus N` splits that SAME box over N GPUs (strong
+scaling, regular rank grid, RCCL ghost-cell halo).  `--n-per-dim 171` gives the 10^7 variant (configs[1]).  The start
+configuration is generated in device memory and is resident in HBM before the timed region.  Prints ONE JSON line
+(rank 0) with `roofline` (force kernel: algorithmic bytes / HIP-event kernel time vs 8 TB/s) and `cpu_baseline` (the
+REAL reference binary oracle/_ref/MarDyn timed on the host cores on a bounded sample of the same workload; the oracle
+restatement is used only if that binary is absent).
 """
 import argparse
 import importlib
@@ -33,28 +36,10 @@ FORCE_BYTES_PER_MOLECULE = 48.0   # read r (24 B) + write F (24 B): SURVEY.md 8(
 # fused force + integration pass (between steps, reduced-memory mode): read r, v (48 B) + write r', v' (48 B); F never
 # reaches HBM and the 120 B integrator pass disappears (SURVEY.md 8(d) force 48 B + integrator 120 B -> 96 B)
 FUSED_BYTES_PER_MOLECULE = 96.0
-PMC_SUMMARY = "r1_g_pmc_summary.json"  # rocprofv3 PMC passes of this workload (tools/collect_profiles.sh)
+PMC_SUMMARY = "r2_pmc_summary.json"  # rocprofv3 PMC passes of this workload (tools/collect_profiles.sh)
 STEP_BYTES_PER_MOLECULE = 292.0   # full step: force 48 + integrator 120 + re-bin 124
 HBM_PEAK_GBS = 8000.0
-
-
-def bcc_box(n_per_dim, seed=1234, jitter=0.1):
-    """Jittered bcc lattice (ParticleCellBase::initCubicGrid layout, /root/reference/src/particleContainer/
-    ParticleCellBase.cpp:73-177) with Maxwell velocities at T*."""
-    rng = np.random.default_rng(seed)
-    n = n_per_dim
-    N = 2 * n ** 3
-    L = (N / RHO) ** (1.0 / 3.0)
-    a = L / n
-    ax = (np.arange(n, dtype=np.float64) + 0.25) * a
-    g = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
-    r = np.concatenate([g, g + 0.5 * a])
-    r += jitter * (rng.random(r.shape) - 0.5)
-    r %= L
-    r[r >= L] = 0.0
-    v = rng.standard_normal(r.shape) * np.sqrt(TEMP)
-    v -= v.mean(0)
-    return L, r, v
+BASELINE_METRIC = "particle-updates/sec (whole node), 10^8 LJ liquid Argon, rc=2.5\u03c3"  # BASELINE.json, verbatim
 
 
 def lj_components(inp):
@@ -90,6 +75,17 @@ MARDYN_XML = """<?xml version='1.0' encoding='UTF-8'?>
 """
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(n_per_dim=50, steps=10, budget_s=150):
     """Reference OpenMP CPU path on the host cores: same liquid (bcc lattice start from the reference's own
     CubicGridGenerator), bounded sample N = 2*n^3, `steps` steps."""
@@ -112,11 +108,12 @@ def cpu_baseline(n_per_dim=50, steps=10, budget_s=150):
             nm = re.search(r"[Nn]umber of molecules[^0-9]*([0-9]+)", out)
             if m:
                 return {"value": float(m.group(1)), "unit": "particle-updates/s", "cores": cores, "kind": "reference",
+                        "cpu": cpu_model(), "host_cpus_visible": len(os.sched_getaffinity(0)),
                         "sample": f"reference MarDyn (AVX2, OpenMP c08, FP64) 1CLJ N={nm.group(1) if nm else N} bcc rho*={RHO} rc={RC}, {steps} steps, {cores} threads"}
     # fallback: the oracle restatement (scalar, 1 core) — only when the reference binary did not travel
     from oracle.oracle import Oracle  # checker, used here only as the timed CPU baseline
     inp = importlib.import_module("ls1-mardyn_amd.inp")
-    Lb, r, v = bcc_box(20)
+    Lb, _ids, r, v = importlib.import_module("ls1-mardyn_amd.synth").bcc_box(20, rho=RHO, temp=TEMP)
     n = len(r)
     orc = Oracle(lj_components(inp).flat(), RC)
     cid = np.zeros(n, np.int32); q = np.tile([1., 0, 0, 0], (n, 1)); D = np.zeros((n, 3))
@@ -127,7 +124,7 @@ def cpu_baseline(n_per_dim=50, steps=10, budget_s=150):
     for _ in range(ksteps):
         orc.step(DT, cid, r, v, q, D, F, M, np.array([Lb] * 3), True)
     dt = time.time() - t0
-    return {"value": n * ksteps / dt, "unit": "particle-updates/s", "cores": 1, "kind": "port",
+    return {"value": n * ksteps / dt, "unit": "particle-updates/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
             "sample": f"oracle/ls1_oracle.c scalar restatement, 1CLJ N={n}, {ksteps} steps, 1 thread"}
 
 
@@ -136,7 +133,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n-per-dim", type=int, default=171, help="bcc cells per dimension per GPU (N = 2 n^3)")
+    ap.add_argument("--n-per-dim", type=int, default=368,
+                    help="bcc cells per dimension of the GLOBAL box (N = 2 n^3; 368 = the 10^8 box of the metric, 171 = configs[1])")
     ap.add_argument("--kernel", type=int, default=0, help="force kernel variant (LS1HIP_FK_*)")
     ap.add_argument("--cic", type=int, default=0, help="cells in cutoff (0 = engine default)")
     ap.add_argument("--split", type=int, default=0, help="lanes per molecule in the LDS LJ kernel (0 = engine default)")
@@ -180,14 +178,16 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         decomp = importlib.import_module("ls1-mardyn_amd.decomp")
-        sim = decomp.build_weak_scaling_box(comps, RC, n, world, rank, local_rank, bcc_box, cic=args.cic or None,
-                                            kernel=args.kernel, stage_through_host=rehearse, loopback=args.loopback)
+        sim = decomp.build_strong_scaling_box(comps, RC, n, world, rank, local_rank, rho=RHO, temp=TEMP,
+                                              cic=args.cic or None, kernel=args.kernel, stage_through_host=rehearse,
+                                              loopback=args.loopback)
         n_total = sim.n_global
         if args.loopback:  # rehearse the count exchange too (skipped otherwise when there is a single rank)
             sim.ex.force_count_exchange = True
     else:
         engine_mod = importlib.import_module("ls1-mardyn_amd.engine")
-        L, r, v = bcc_box(n)
+        synth = importlib.import_module("ls1-mardyn_amd.synth")
+        L = synth.box_length(n, RHO)
         eng = engine_mod.DeviceEngine(local_rank)
         eng.set_components(comps, RC)
         if args.cic:
@@ -196,9 +196,16 @@ def main():
         if args.split:
             eng.set_option("lj_split", args.split)
         eng.set_domain([L, L, L])
-        N = len(r)
-        eng.upload(np.arange(1, N + 1, dtype=np.uint64), np.zeros(N, np.int32), r, v)
-        del r, v
+        N = 2 * n ** 3
+        dev = torch.device("cuda", local_rank)
+        eng.upload_begin(N)
+        for ids_t, r_t, v_t in synth.bcc_chunks_device(torch, dev, n, rho=RHO, temp=TEMP):
+            torch.cuda.synchronize()
+            eng.upload_chunk_device(ids_t.numel(), ids_t.data_ptr(), 0, r_t.data_ptr(), v_t.data_ptr())
+        del ids_t, r_t, v_t
+        eng.upload_end()
+        torch.cuda.empty_cache()
+        assert eng.count()[0] == N
         eng.rebin(); eng.halo(); eng.forces(0)
         sim = None
         n_total = N
@@ -275,12 +282,13 @@ def main():
         achieved = alg_bytes_total / (force_ms / 1e3) / 1e9
         value = n_total * args.steps / elapsed
         out = {
-            "metric": "particle-updates/sec (whole node), 1CLJ liquid Argon-like LJ, rc=2.5 sigma",
+            "metric": BASELINE_METRIC if n == 368 else f"particle-updates/sec (whole node), N={n_total} LJ liquid Argon, rc=2.5\u03c3",
             "value": value, "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"1CLJ Lennard-Jones liquid, N={n_total} (2*{n}^3 per GPU), rho*={RHO}, rc={RC} sigma, "
-                                   f"dt={DT}, T*={TEMP}, NVE full time step (kick-drift, re-bin, halo, forces, kick), FP64",
+            "config": {"workload": f"1CLJ Lennard-Jones liquid, N={n_total} = 2*{n}^3 (global box, split over {world} GPU(s)), "
+                                   f"rho*={RHO}, rc={RC} sigma, dt={DT}, T*={TEMP}, NVE full time step (kick-drift, re-bin, halo, "
+                                   f"forces, kick) with per-step U_pot / virial / sum mv^2, FP64",
                        "molecules_per_gpu": n_local, "decomposition": getattr(sim, "grid_desc", "single GPU, periodic images local"),
                        "force_kernel": e.get_option("force_kernel"), "cells_in_cutoff": e.get_option("cells_in_cutoff"),
                        "integration": ("fused into the force pass between steps (reduced-memory mode), last step separate"

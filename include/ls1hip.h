@@ -119,6 +119,35 @@ int ls1hip_get_grid(const ls1hip_ctx* ctx, int dims[3], double cell_len[3], int*
  * q and D may be NULL (unit quaternion / zero angular momentum). */
 int ls1hip_upload(ls1hip_ctx* ctx, size_t n, const uint64_t* id, const int32_t* cid, const double* r, const double* v,
 				  const double* q, const double* D);
+/* Streaming form of ls1hip_upload for phase spaces that should never exist twice on the host (the 10^8 restart case,
+ * SURVEY.md 8f-3): announce an upper bound of the total (it sizes the device arrays), hand over any number of chunks,
+ * finish; the molecules actually handed over become the molecule set.  Chunks are copied raw to the device
+ * and transposed into the device SoA there (no host-side Molecule objects, no host-side SoA copies).
+ * ls1hip_upload_records takes the records of the reference's binary checkpoint as they lie in the file:
+ *   LS1HIP_REC_ICRVQD 116 B {id u64, cid u32 (1-based), r 3 f64, v 3 f64, q 4 f64, D 3 f64}
+ *                     (FullMolecule::writeBinary, molecules/FullMolecule.cpp:451-473; Domain.cpp:572-595),
+ *   LS1HIP_REC_ICRV    60 B {id, cid, r, v},  LS1HIP_REC_IRV 56 B {id, r, v}   (io/BinaryReader.cpp:103-108,179-213;
+ *                     q = (1,0,0,0), D = 0, and cid = 1 for IRV).
+ * Replaces: BinaryReader::readPhaseSpace -> ParticleContainer::addParticle (io/BinaryReader.cpp:140-260).
+ * Errors (molecule outside the bounding box, wrong component id) are reported by ls1hip_upload_end. */
+#define LS1HIP_REC_ICRVQD 0
+#define LS1HIP_REC_ICRV 1
+#define LS1HIP_REC_IRV 2
+int ls1hip_upload_begin(ls1hip_ctx* ctx, size_t n_total);
+int ls1hip_upload_chunk(ls1hip_ctx* ctx, size_t n, const uint64_t* id, const int32_t* cid, const double* r,
+						const double* v, const double* q, const double* D);
+int ls1hip_upload_records(ls1hip_ctx* ctx, size_t n, const void* records, int format);
+/* ls1hip_upload_chunk for producers that already live on the GPU (generators, RCCL receive buffers): the arrays are
+ * DEVICE pointers on the context's device, complete when the call is made (synchronise the producing stream first);
+ * they may be released when the call returns. */
+int ls1hip_upload_chunk_device(ls1hip_ctx* ctx, size_t n, const uint64_t* dev_id, const int32_t* dev_cid,
+							   const double* dev_r, const double* dev_v, const double* dev_q, const double* dev_D);
+int ls1hip_upload_end(ls1hip_ctx* ctx);
+/* Owned molecules [first, first + n) in device order as ICRVQD records (the payload of the reference's binary
+ * checkpoint, written by ParticleContainer iteration + FullMolecule::writeBinary in io/CheckpointWriter /
+ * Domain::writeCheckpoint, Domain.cpp:572-595); positions are wrapped into the box. */
+int ls1hip_download_records(ls1hip_ctx* ctx, size_t first, size_t n, void* records);
+
 /* Number of molecules owned by this rank / halo copies currently held. */
 int ls1hip_count(const ls1hip_ctx* ctx, size_t* n_owned, size_t* n_halo);
 
@@ -199,6 +228,14 @@ int ls1hip_long_range_homogeneous(ls1hip_ctx* ctx, const uint64_t* n_per_compone
  * inside: the loop body of Simulation::simulate (Simulation.cpp:979-1167) for an NVE run without plugins.
  * out6 (may be NULL) = {upot, virial, summv2, sumIw2, N, rotDOF} of the LAST step. */
 int ls1hip_run(ls1hip_ctx* ctx, double dt, unsigned long nsteps, double* out6);
+/* The global values of EVERY step of the last ls1hip_run, one row {upot, virial, summv2, sumIw2, N, rotDOF} per step,
+ * oldest first (the last 4096 steps are kept): what Leapfrog::transition2to3 hands to Domain::setLocalSummv2 / SumIw2
+ * (integrators/Leapfrog.cpp:115-150) and VectorizedCellProcessor::endTraversal to setLocalUpot / Virial in every step,
+ * i.e. the inputs of Domain::calculateGlobalValues (Domain.cpp:151-181, called per step at Simulation.cpp:1099-1103).
+ * The rows are written by the reduction kernels on the device, no host round trip inside the run; in the fused mode
+ * the kinetic sum comes out of the force pass's own epilogue.  Columns 2-5 are NaN for steps whose kinetic sums were not
+ * computed (unfused NVE steps before the last).  rows may be NULL to query *nrows. */
+int ls1hip_run_log(ls1hip_ctx* ctx, size_t cap_rows, double* rows, size_t* nrows);
 
 /* ---- multi-GPU plumbing: packed buffers a host transport (RCCL via torch.distributed, MPI, ...) moves ---------
  * Wire formats (little endian, FP64): leaving molecule = 15 doubles {id(as bits), cid(as bits), r3, v3, q4, D3}

@@ -33,6 +33,13 @@ SYMBOLS = {
     "ls1hip_set_domain": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int, _ip]),
     "ls1hip_get_grid": (C.c_int, [C.c_void_p, _ip, _dp, _ip]),
     "ls1hip_upload": (C.c_int, [C.c_void_p, C.c_size_t, _u64p, _i32p, _dp, _dp, _dp, _dp]),
+    "ls1hip_upload_begin": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "ls1hip_upload_chunk": (C.c_int, [C.c_void_p, C.c_size_t, _u64p, _i32p, _dp, _dp, _dp, _dp]),
+    "ls1hip_upload_chunk_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
+    "ls1hip_upload_records": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
+    "ls1hip_upload_end": (C.c_int, [C.c_void_p]),
+    "ls1hip_download_records": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
     "ls1hip_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "ls1hip_download_state": (C.c_int, [C.c_void_p, C.c_size_t, _u64p, _i32p, _dp, _dp, _dp, _dp]),
     "ls1hip_download_forces": (C.c_int, [C.c_void_p, C.c_size_t, _dp, _dp, _dp]),
@@ -47,6 +54,7 @@ SYMBOLS = {
     "ls1hip_set_thermostat": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     "ls1hip_long_range_homogeneous": (C.c_int, [C.c_void_p, _u64p, C.c_double, _dp, _dp]),
     "ls1hip_run": (C.c_int, [C.c_void_p, C.c_double, C.c_ulong, _dp]),
+    "ls1hip_run_log": (C.c_int, [C.c_void_p, C.c_size_t, _dp, C.POINTER(C.c_size_t)]),
     "ls1hip_export_counts": (C.c_int, [C.c_void_p, C.c_int, _u64p]),
     "ls1hip_export_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "ls1hip_export_pack_dirs": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_size_t]),
@@ -62,6 +70,8 @@ SYMBOLS = {
 LEAVING_DOUBLES = 15
 HALO_DOUBLES = 9
 FK_AUTO, FK_GENERIC, FK_LDS_LIST = 0, 1, 2
+REC_ICRVQD, REC_ICRV, REC_IRV = 0, 1, 2
+REC_BYTES = {REC_ICRVQD: 116, REC_ICRV: 60, REC_IRV: 56}
 
 
 class Ls1HipError(RuntimeError):

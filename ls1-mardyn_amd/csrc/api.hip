@@ -163,6 +163,8 @@ extern "C" int ls1hip_destroy(ls1hip_ctx* c) {
 	dfree(c->d_ct);
 	dfree(c->d_cnt);
 	dfree(c->d_stage);
+	dfree(c->d_steplog);
+	if (c->d_ingest) hipFree(c->d_ingest);
 	if (c->h_cnt) hipHostFree(c->h_cnt);
 	timer_free(c->t_force); timer_free(c->t_integrate); timer_free(c->t_rebin); timer_free(c->t_halo);
 	hipStreamDestroy(c->stream);
@@ -512,64 +514,134 @@ static int alloc_mol(ls1hip_ctx* c, size_t n) {
 	return 0;
 }
 
-template <class T>
-static int h2d(ls1hip_ctx* c, T* dst, const std::vector<T>& src) {
-	if (src.empty()) return 0;
-	HIPCHK(c, hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
-	return 0;
+// ---- streaming upload: chunks are copied raw into a device staging buffer and transposed into the SoA on the device ----
+constexpr size_t STEPLOG_ROWS = 4096;  // per-step globals kept on the device for ls1hip_run_log (ring)
+constexpr size_t INGEST_CHUNK = (size_t)1 << 22;  // molecules per staging pass (116 B each)
+
+static IngestArgs ingest_args(ls1hip_ctx* c, size_t n) {
+	IngestArgs a;
+	a.dst = c->mol[0];
+	a.has_rot = c->h_ct.has_rot;
+	a.ncomp = c->h_ct.ncomp;
+	for (int d = 0; d < 3; ++d) {
+		a.bmin[d] = c->g.bmin[d];
+		a.bmax[d] = c->g.bmax[d];
+	}
+	a.cnt = c->d_cnt;
+	a.at = (uint32_t)c->ingest_at;
+	a.first = (uint32_t)c->ingest_at;
+	a.n = (uint32_t)n;
+	return a;
 }
 
-extern "C" int ls1hip_upload(ls1hip_ctx* c, size_t n, const uint64_t* id, const int32_t* cid, const double* r,
-							 const double* v, const double* q, const double* D) {
+extern "C" int ls1hip_upload_begin(ls1hip_ctx* c, size_t n) {
 	if (!c) return LS1HIP_EINVAL;
 	REQUIRE(c, c->have_domain, "ls1hip_set_domain must be called first");
-	REQUIRE(c, n == 0 || (id && r && v), "null molecule arrays");
 	REQUIRE(c, n < 0x7fff0000ull, "too many molecules for 32-bit indices");
 	HIPCHK(c, hipSetDevice(c->device));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	int rc = alloc_mol(c, n);
 	if (rc) return rc;
-	const bool rot = c->h_ct.has_rot;
-	for (size_t i = 0; i < n; ++i) {
-		for (int d = 0; d < 3; ++d)
-			REQUIRE(c, r[3 * i + d] >= c->g.bmin[d] && r[3 * i + d] < c->g.bmax[d],
-					"molecule %zu lies outside the bounding box of this rank", i);
-		REQUIRE(c, !cid || (cid[i] >= 0 && cid[i] < c->h_ct.ncomp), "molecule %zu has a wrong component id", i);
+	const size_t bytes = std::min(std::max<size_t>(n, 1), INGEST_CHUNK) * 116 + 64;
+	if (bytes > c->ingest_bytes) {
+		if (c->d_ingest) hipFree(c->d_ingest);
+		c->d_ingest = nullptr;
+		c->ingest_bytes = 0;
+		hipError_t e = hipMalloc(&c->d_ingest, bytes);
+		if (e != hipSuccess) FAIL(c, LS1HIP_ENOMEM, "hipMalloc(%zu bytes) for the upload staging failed: %s", bytes, hipGetErrorString(e));
+		c->ingest_bytes = bytes;
 	}
 	c->cur = 0;
-	MolSoA& m = c->mol[0];
-	std::vector<double> t0(n), t1(n), t2(n);
-	auto put3 = [&](const double* src, int stride, int o, double* d0, double* d1, double* d2) -> int {
-		for (size_t i = 0; i < n; ++i) {
-			t0[i] = src[stride * i + o];
-			t1[i] = src[stride * i + o + 1];
-			t2[i] = src[stride * i + o + 2];
-		}
-		int e;
-		if ((e = h2d(c, d0, t0)) || (e = h2d(c, d1, t1)) || (e = h2d(c, d2, t2))) return e;
-		HIPCHK(c, hipStreamSynchronize(c->stream));
-		return 0;
-	};
-	if (n) {
-		if ((rc = put3(r, 3, 0, m.x, m.y, m.z)) || (rc = put3(v, 3, 0, m.vx, m.vy, m.vz))) return rc;
-		if (rot) {
-			std::vector<double> qq(4 * n), dd(3 * n, 0.);
-			for (size_t i = 0; i < n; ++i) {
-				if (q) for (int k = 0; k < 4; ++k) qq[4 * i + k] = q[4 * i + k];
-				else { qq[4 * i] = 1.; qq[4 * i + 1] = qq[4 * i + 2] = qq[4 * i + 3] = 0.; }
-			}
-			if (D) dd.assign(D, D + 3 * n);
-			for (size_t i = 0; i < n; ++i) t0[i] = qq[4 * i];
-			if ((rc = h2d(c, m.q0, t0))) return rc;
-			HIPCHK(c, hipStreamSynchronize(c->stream));
-			if ((rc = put3(qq.data(), 4, 1, m.q1, m.q2, m.q3)) || (rc = put3(dd.data(), 3, 0, m.Dx, m.Dy, m.Dz))) return rc;
-		}
-		std::vector<int32_t> cc(n, 0);
-		if (cid) cc.assign(cid, cid + n);
-		HIPCHK(c, hipMemcpyAsync(m.id, id, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-		HIPCHK(c, hipMemcpyAsync(m.cid, cc.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-		HIPCHK(c, hipStreamSynchronize(c->stream));
+	HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(DevCounters), c->stream));
+	c->ingest_open = true;
+	c->ingest_total = n;
+	c->ingest_at = 0;
+	c->n_real = 0;
+	c->n_halo = 0;
+	c->binned = c->halo_valid = c->forces_valid = false;
+	c->pos_in_F = false;
+	c->fused_split = 0;
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_upload_chunk(ls1hip_ctx* c, size_t n, const uint64_t* id, const int32_t* cid, const double* r,
+								   const double* v, const double* q, const double* D) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, c->ingest_open, "ls1hip_upload_begin must be called first");
+	REQUIRE(c, n == 0 || (id && r && v), "null molecule arrays");
+	REQUIRE(c, c->ingest_at + n <= c->ingest_total, "more molecules than announced to ls1hip_upload_begin");
+	HIPCHK(c, hipSetDevice(c->device));
+	const bool rot = c->h_ct.has_rot;
+	for (size_t o = 0; o < n; o += INGEST_CHUNK) {
+		const size_t m = std::min(INGEST_CHUNK, n - o);
+		char* b = (char*)c->d_ingest;
+		uint64_t* did = (uint64_t*)b;
+		double* dr = (double*)(b + 8 * m);
+		double* dv = dr + 3 * m;
+		double* dq = dv + 3 * m;
+		double* dD = dq + 4 * m;
+		int32_t* dc = (int32_t*)(dD + 3 * m);
+		HIPCHK(c, hipMemcpyAsync(did, id + o, m * 8, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(c, hipMemcpyAsync(dr, r + 3 * o, m * 24, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(c, hipMemcpyAsync(dv, v + 3 * o, m * 24, hipMemcpyHostToDevice, c->stream));
+		if (rot && q) HIPCHK(c, hipMemcpyAsync(dq, q + 4 * o, m * 32, hipMemcpyHostToDevice, c->stream));
+		if (rot && D) HIPCHK(c, hipMemcpyAsync(dD, D + 3 * o, m * 24, hipMemcpyHostToDevice, c->stream));
+		if (cid) HIPCHK(c, hipMemcpyAsync(dc, cid + o, m * 4, hipMemcpyHostToDevice, c->stream));
+		launch_ingest_aos(ingest_args(c, m), did, cid ? dc : nullptr, dr, dv, (rot && q) ? dq : nullptr, (rot && D) ? dD : nullptr,
+						  c->stream);
+		HIPCHK(c, hipGetLastError());
+		HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging buffer is reused by the next pass
+		c->ingest_at += m;
 	}
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_upload_chunk_device(ls1hip_ctx* c, size_t n, const uint64_t* dev_id, const int32_t* dev_cid,
+										  const double* dev_r, const double* dev_v, const double* dev_q, const double* dev_D) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, c->ingest_open, "ls1hip_upload_begin must be called first");
+	REQUIRE(c, n == 0 || (dev_id && dev_r && dev_v), "null molecule arrays");
+	REQUIRE(c, c->ingest_at + n <= c->ingest_total, "more molecules than announced to ls1hip_upload_begin");
+	HIPCHK(c, hipSetDevice(c->device));
+	const bool rot = c->h_ct.has_rot;
+	launch_ingest_aos(ingest_args(c, n), dev_id, dev_cid, dev_r, dev_v, rot ? dev_q : nullptr, rot ? dev_D : nullptr, c->stream);
+	HIPCHK(c, hipGetLastError());
+	HIPCHK(c, hipStreamSynchronize(c->stream));  // the caller may release its buffers when the call returns
+	c->ingest_at += n;
+	return LS1HIP_OK;
+}
+
+static size_t record_bytes(int format) { return format == LS1HIP_REC_ICRVQD ? 116 : (format == LS1HIP_REC_ICRV ? 60 : 56); }
+
+extern "C" int ls1hip_upload_records(ls1hip_ctx* c, size_t n, const void* records, int format) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, c->ingest_open, "ls1hip_upload_begin must be called first");
+	REQUIRE(c, format == LS1HIP_REC_ICRVQD || format == LS1HIP_REC_ICRV || format == LS1HIP_REC_IRV, "unknown record format %d", format);
+	REQUIRE(c, n == 0 || records, "null record buffer");
+	REQUIRE(c, c->ingest_at + n <= c->ingest_total, "more molecules than announced to ls1hip_upload_begin");
+	HIPCHK(c, hipSetDevice(c->device));
+	const size_t rb = record_bytes(format);
+	for (size_t o = 0; o < n; o += INGEST_CHUNK) {
+		const size_t m = std::min(INGEST_CHUNK, n - o);
+		HIPCHK(c, hipMemcpyAsync(c->d_ingest, (const char*)records + o * rb, m * rb, hipMemcpyHostToDevice, c->stream));
+		launch_ingest_records(ingest_args(c, m), c->d_ingest, format, c->stream);
+		HIPCHK(c, hipGetLastError());
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		c->ingest_at += m;
+	}
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_upload_end(ls1hip_ctx* c) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, c->ingest_open, "ls1hip_upload_begin must be called first");
+	HIPCHK(c, hipSetDevice(c->device));
+	c->ingest_open = false;
+	if (c->d_ingest) hipFree(c->d_ingest);  // the staging buffer is only needed while a phase space streams in
+	c->d_ingest = nullptr;
+	c->ingest_bytes = 0;
+	const size_t n = c->ingest_at;  // the announced total is an upper bound (it sized the device arrays)
+	const bool rot = c->h_ct.has_rot;
 	// forces start at zero (a freshly read phase space has F = M = 0: FullMolecule.cpp:44-45)
 	HIPCHK(c, hipMemsetAsync(c->frc.Fx, 0, c->cap_real * sizeof(double), c->stream));
 	HIPCHK(c, hipMemsetAsync(c->frc.Fy, 0, c->cap_real * sizeof(double), c->stream));
@@ -579,18 +651,27 @@ extern "C" int ls1hip_upload(ls1hip_ctx* c, size_t n, const uint64_t* id, const 
 		HIPCHK(c, hipMemsetAsync(c->frc.My, 0, c->cap_real * sizeof(double), c->stream));
 		HIPCHK(c, hipMemsetAsync(c->frc.Mz, 0, c->cap_real * sizeof(double), c->stream));
 	}
-	HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, sizeof(DevCounters), c->stream));
+	HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->d_cnt, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	if (c->h_cnt->err_ingest)
+		FAIL(c, LS1HIP_EINVAL, "%u uploaded molecule(s) lie outside the bounding box of this rank or carry a wrong component id (e.g. molecule %u)",
+			 c->h_cnt->err_ingest, c->h_cnt->err_ingest_first);
 	c->h_cnt->n_real = (uint32_t)n;
 	HIPCHK(c, hipMemcpyAsync(&c->d_cnt->n_real, &c->h_cnt->n_real, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	c->n_real = n;
-	c->n_halo = 0;
-	c->binned = false;
-	c->halo_valid = false;
-	c->forces_valid = false;
-	c->pos_in_F = false;
-	c->fused_split = 0;
 	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_upload(ls1hip_ctx* c, size_t n, const uint64_t* id, const int32_t* cid, const double* r,
+							 const double* v, const double* q, const double* D) {
+	int rc = ls1hip_upload_begin(c, n);
+	if (rc) return rc;
+	if ((rc = ls1hip_upload_chunk(c, n, id, cid, r, v, q, D))) {
+		c->ingest_open = false;
+		return rc;
+	}
+	return ls1hip_upload_end(c);
 }
 
 // stream of the halo phase: the second stream while an inner-cell force pass is in flight on the main one
@@ -753,6 +834,7 @@ static int launch_forces(ls1hip_ctx* c, int which, bool fuse = false, double dt 
 		P.fuse = 1;
 		P.dt = dt;
 		P.dt_inv2m = (.5 * dt) / c->h_ct.mass[0];  // as k_kick_then_kick_drift: dt_halve / mass
+		P.mass = c->h_ct.mass[0];
 		P.vx = m.vx; P.vy = m.vy; P.vz = m.vz;
 	}
 	uint32_t nblocks = 0;
@@ -778,7 +860,7 @@ static int launch_forces(ls1hip_ctx* c, int which, bool fuse = false, double dt 
 		const double nbrs = vol > 0. ? (double)c->n_real / vol * 4.18879 * c->rc * c->rc * c->rc : 0.;
 		launch_force_generic(P, c->one_clj, c->opt_vi != 0, c->h_ct.has_rot != 0, c->stream, &nblocks, nbrs);
 	}
-	launch_force_reduce(c->d_cnt, c->d_partials, nblocks, c->d_stage, c->stream, first_pass && !c->opt_count_pairs);
+	launch_force_reduce(c->d_cnt, c->d_partials, nblocks, c->d_stage, c->stream, first_pass && !c->opt_count_pairs, fuse, c->log_row);
 	HIPCHK(c, hipGetLastError());
 	return LS1HIP_OK;
 }
@@ -908,7 +990,7 @@ extern "C" int ls1hip_kick(ls1hip_ctx* c, double dt_half, double* summv2, double
 		TimedScope ts(c, c->t_integrate);
 		uint32_t nb = 0;
 		launch_kick(integ_args(c, dt_half), c->stream, &nb);
-		launch_kin_reduce(c->d_cnt, c->d_partials, nb, c->stream, c->thermostat_on ? c->thermostat_T : 0.);
+		launch_kin_reduce(c->d_cnt, c->d_partials, nb, c->stream, c->thermostat_on ? c->thermostat_T : 0., c->log_row_kin);
 	}
 	if (summv2 || sumIw2 || n || rot_dof) {
 		int rc = sync_counters(c);
@@ -1029,8 +1111,21 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 	// reference's reduced-memory scheme); the last step is unfused so that F and the kinetic sums are available.
 	const bool fuse = c->opt_fuse && can_fuse(c);
 	bool advanced = false;  // the previous force pass already did kick + kick + drift
+	// step log: one row {U_pot, virial, sum m v^2, sum I w^2, N, rotDOF} per step, written by the reductions on the device
+	if (!c->d_steplog) {
+		int rc0 = dalloc(c, &c->d_steplog, STEPLOG_ROWS * 6);
+		if (rc0) return rc0;
+	}
+	HIPCHK(c, hipMemsetAsync(c->d_steplog, 0xff, std::min<size_t>(nsteps, STEPLOG_ROWS) * 6 * sizeof(double), c->stream));  // NaN = not computed
+	struct LogGuard {
+		ls1hip_ctx* c;
+		~LogGuard() { c->log_row = c->log_row_kin = nullptr; }
+	} log_guard{c};
+	c->steplog_steps = 0;
 	for (unsigned long s = 0; s < nsteps; ++s) {
 		int rc;
+		c->log_row = c->d_steplog + (s % STEPLOG_ROWS) * 6;                         // forces of step s
+		c->log_row_kin = s ? c->d_steplog + ((s - 1) % STEPLOG_ROWS) * 6 : nullptr;  // a kick at the head of step s ends step s-1
 		if (advanced) {
 			// nothing to integrate: positions wait in the force arrays for the re-binning pass
 		} else if (s == 0) {
@@ -1068,6 +1163,7 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 		}
 		if (rc) return rc;
 		if (s + 1 == nsteps) {
+			c->log_row_kin = c->log_row;
 			if ((rc = ls1hip_kick(c, 0.5 * dt, nullptr, nullptr, nullptr, nullptr))) return rc;
 			if (c->thermostat_on) {
 				TimedScope ts(c, c->t_integrate);
@@ -1075,6 +1171,7 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 			}
 		}
 	}
+	c->steplog_steps = nsteps;
 	int rc = sync_counters(c);
 	if (rc) return rc;
 	if (out6) {
@@ -1084,6 +1181,22 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 		out6[4] = (double)c->h_cnt->kin_n;
 		out6[5] = (double)c->h_cnt->kin_rotdof;
 	}
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_run_log(ls1hip_ctx* c, size_t cap_rows, double* rows, size_t* nrows) {
+	if (!c) return LS1HIP_EINVAL;
+	const size_t have = std::min<size_t>(c->steplog_steps, STEPLOG_ROWS);
+	if (nrows) *nrows = have;
+	if (!rows || have == 0) return LS1HIP_OK;
+	REQUIRE(c, cap_rows >= have, "buffer too small: %zu < %zu rows", cap_rows, have);
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	// oldest row first: the log is a ring over the step number (at most two contiguous runs)
+	const size_t first = (c->steplog_steps - have) % STEPLOG_ROWS;
+	const size_t n1 = std::min(have, STEPLOG_ROWS - first);
+	HIPCHK(c, hipMemcpy(rows, c->d_steplog + 6 * first, n1 * 6 * sizeof(double), hipMemcpyDeviceToHost));
+	if (have > n1) HIPCHK(c, hipMemcpy(rows + 6 * n1, c->d_steplog, (have - n1) * 6 * sizeof(double), hipMemcpyDeviceToHost));
 	return LS1HIP_OK;
 }
 
@@ -1134,6 +1247,43 @@ extern "C" int ls1hip_download_state(ls1hip_ctx* c, size_t cap, uint64_t* id, in
 	if (D && (rc = d2h3(c, n, c->h_ct.has_rot ? m.Dx : nullptr, c->h_ct.has_rot ? m.Dy : nullptr,
 						c->h_ct.has_rot ? m.Dz : nullptr, D, 3, 0)))
 		return rc;
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_download_records(ls1hip_ctx* c, size_t first, size_t n, void* records) {
+	if (!c) return LS1HIP_EINVAL;
+	HIPCHK(c, hipSetDevice(c->device));
+	REQUIRE(c, !c->fused_split, "state is half advanced (complete the fused which=2 pass first)");
+	REQUIRE(c, first + n <= c->n_real, "record range [%zu, %zu) exceeds the %zu owned molecules", first, first + n, c->n_real);
+	REQUIRE(c, n == 0 || records, "null record buffer");
+	int rc;
+	if ((rc = materialise_positions(c))) return rc;
+	void* d = nullptr;
+	const size_t chunk = std::min(std::max<size_t>(n, 1), INGEST_CHUNK);
+	hipError_t e = hipMalloc(&d, chunk * 116);
+	if (e != hipSuccess) FAIL(c, LS1HIP_ENOMEM, "hipMalloc(%zu bytes) failed: %s", chunk * 116, hipGetErrorString(e));
+	EgressArgs a;
+	a.src = c->mol[c->cur];
+	a.x = a.src.x; a.y = a.src.y; a.z = a.src.z;
+	a.has_rot = c->h_ct.has_rot;
+	for (int k = 0; k < 3; ++k) {
+		a.bmin[k] = c->g.bmin[k];
+		a.bmax[k] = c->g.bmax[k];
+		a.len[k] = c->global_len[k];
+		// a side is wrapped here when its image lives on this rank (single-rank periodic box)
+		a.periodic[k] = c->nbr[13 + (k == 0 ? 1 : (k == 1 ? 3 : 9))] == c->my_rank && c->nbr[13 - (k == 0 ? 1 : (k == 1 ? 3 : 9))] == c->my_rank;
+	}
+	for (size_t o = 0; o < n && !rc; o += chunk) {
+		const size_t m = std::min(chunk, n - o);
+		a.first = (uint32_t)(first + o);
+		a.n = (uint32_t)m;
+		launch_egress_records(a, d, c->stream);
+		if (hipMemcpyAsync((char*)records + o * 116, d, m * 116, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+			hipStreamSynchronize(c->stream) != hipSuccess)
+			rc = LS1HIP_EHIP;
+	}
+	hipFree(d);
+	if (rc) FAIL(c, rc, "record download failed");
 	return LS1HIP_OK;
 }
 

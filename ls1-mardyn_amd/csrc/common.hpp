@@ -47,6 +47,8 @@ struct DevCounters {
 	uint32_t exp_halo[27];
 	uint32_t err_lost;     // molecules that left the halo region
 	uint32_t err_overflow; // capacity overflows
+	uint32_t err_ingest;   // uploaded molecules outside the bounding box of this rank / with a wrong component id
+	uint32_t err_ingest_first;  // index (in upload order) of one offending molecule
 	unsigned long long dist_checks, pairs_in_range;
 	double macro[4];       // u6, uX, rf, virial of the current traversal
 	double kin[2];         // sum m v^2, sum I w^2
@@ -74,7 +76,7 @@ struct ForceParams {
 	int inner_box, inner_lo[3], inner_n[3];
 	// fused force -> kick -> kick -> drift (LJ fast path only): v updated in place, new positions written to Fx/Fy/Fz
 	int fuse;
-	double dt, dt_inv2m;
+	double dt, dt_inv2m, mass;
 	double *vx, *vy, *vz;
 	// 1CLJ fast-path scalars
 	double eps24, sig2, shift6, rc2;
@@ -159,6 +161,15 @@ struct ls1hip_ctx {
 	int timing_on = 0;  // 0 off, 1 all phases, 2 force passes only
 	ls1::Timer t_force, t_integrate, t_rebin, t_halo;
 	std::vector<void*> allocs;
+	// per-step globals of ls1hip_run (ls1hip_run_log): rows of 6 doubles, written by the reduction kernels
+	double* d_steplog = nullptr;
+	double *log_row = nullptr, *log_row_kin = nullptr;  // rows the next force / kinetic reduction refreshes (null outside ls1hip_run)
+	size_t steplog_steps = 0;
+	// streaming upload (ls1hip_upload_begin / _chunk / _records / _end)
+	bool ingest_open = false;
+	size_t ingest_total = 0, ingest_at = 0;
+	void* d_ingest = nullptr;  // device staging of one chunk
+	size_t ingest_bytes = 0;
 };
 
 namespace ls1 {
@@ -215,6 +226,30 @@ struct PackSegments {
 };
 void launch_pack_segments(const PackSegments& seg, const double* src, double* dst, hipStream_t s);
 
+// device-side ingest / egress (kernels_ingest.hip)
+struct IngestArgs {
+	MolSoA dst;
+	bool has_rot;
+	int ncomp;
+	double bmin[3], bmax[3];
+	DevCounters* cnt;
+	uint32_t at;     // first destination index
+	uint32_t first;  // index of the chunk's first molecule in upload order (error reporting)
+	uint32_t n;
+};
+void launch_ingest_aos(const IngestArgs& a, const uint64_t* id, const int32_t* cid, const double* r, const double* v,
+					   const double* q, const double* D, hipStream_t s);
+void launch_ingest_records(const IngestArgs& a, const void* rec, int fmt, hipStream_t s);
+struct EgressArgs {
+	MolSoA src;
+	const double *x, *y, *z;  // current positions (may differ from src.x/y/z in the fused / list-reuse modes)
+	bool has_rot;
+	int periodic[3];
+	double bmin[3], bmax[3], len[3];
+	uint32_t first, n;
+};
+void launch_egress_records(const EgressArgs& a, void* rec, hipStream_t s);
+
 void launch_force_generic(const ForceParams& p, bool one_clj, bool with_vi, bool has_rot, hipStream_t s, uint32_t* nblocks,
 						  double expected_neighbours = 0.);
 // LDS-tiled 1CLJ kernel (kernels_force_lj.hip); returns false if it cannot handle the configuration
@@ -223,8 +258,10 @@ bool launch_force_lj(const ForceParams& p, hipStream_t s, uint32_t* nblocks, dou
 // brick-tiled multi-site kernel (kernels_force_ms.hip); returns false if it cannot handle the configuration
 bool launch_force_ms(const ForceParams& p, bool with_vi, bool has_rot, hipStream_t s, uint32_t* nblocks, size_t partials_cap,
 					 double mean_per_cell, BrickLists* bl);
+// kin_in_slot1: the partials' slot 1 carries sum m v^2 of a fused force + integration pass (goes to cnt->kin[0], not to
+// the macroscopic sums); log (may be null): the step-log row {U_pot, virial, sum m v^2, sum I w^2, N, rotDOF} to refresh
 void launch_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, double* stage, hipStream_t s,
-						 bool overwrite = false);
+						 bool overwrite = false, bool kin_in_slot1 = false, double* log = nullptr);
 void launch_clear_macro(DevCounters* cnt, hipStream_t s);
 
 struct IntegArgs {
@@ -240,7 +277,8 @@ struct IntegArgs {
 void launch_kick_drift(const IntegArgs& a, hipStream_t s);
 void launch_kick(const IntegArgs& a, hipStream_t s, uint32_t* nblocks);
 void launch_kick_then_kick_drift(const IntegArgs& a, hipStream_t s);
-void launch_kin_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, hipStream_t s, double target_T);
+void launch_kin_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, hipStream_t s, double target_T,
+					   double* log = nullptr);
 void launch_scale(const IntegArgs& a, double beta_trans, double beta_rot, bool from_device, hipStream_t s);
 
 }  // namespace ls1

@@ -290,7 +290,8 @@ __global__ void __launch_bounds__(256) k_force_reduce1(const double* partials, u
 	__syncthreads();
 	if (threadIdx.x < 4) stage[blockIdx.x * 4 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
-__global__ void __launch_bounds__(RED_BLOCKS) k_force_reduce2(DevCounters* cnt, const double* stage, int overwrite) {
+__global__ void __launch_bounds__(RED_BLOCKS) k_force_reduce2(DevCounters* cnt, const double* stage, int overwrite, int kin_in_slot1,
+															   double* log) {
 	double v[4];
 	for (int k = 0; k < 4; ++k) v[k] = stage[threadIdx.x * 4 + k];
 	__shared__ double red[RED_BLOCKS / 64][4];
@@ -299,20 +300,43 @@ __global__ void __launch_bounds__(RED_BLOCKS) k_force_reduce2(DevCounters* cnt, 
 	if (lane == 0)
 		for (int k = 0; k < 4; ++k) red[w][k] = v[k];
 	__syncthreads();
-	if (threadIdx.x < 4) {
-		double s = 0.;
-		for (int i = 0; i < RED_BLOCKS / 64; ++i) s += red[i][threadIdx.x];
-		cnt->macro[threadIdx.x] = overwrite ? s : cnt->macro[threadIdx.x] + s;  // first pass of a traversal starts the sums
+	if (threadIdx.x == 0) {
+		double s[4];
+		for (int k = 0; k < 4; ++k) {
+			s[k] = 0.;
+			for (int i = 0; i < RED_BLOCKS / 64; ++i) s[k] += red[i][k];
+		}
+		if (kin_in_slot1) {
+			// fused force + integration pass: slot 1 is sum m v^2 after the post-force kick (Leapfrog.cpp:115-131)
+			cnt->kin[0] = overwrite ? s[1] : cnt->kin[0] + s[1];
+			cnt->kin[1] = 0.;
+			cnt->kin_n = cnt->n_real;
+			cnt->kin_rotdof = 0;
+			s[1] = 0.;
+		}
+		for (int k = 0; k < 4; ++k) cnt->macro[k] = overwrite ? s[k] : cnt->macro[k] + s[k];  // first pass of a traversal starts the sums
+		if (log) {
+			// VectorizedCellProcessor::endTraversal (VectorizedCellProcessor.cpp:155-156) + the kinetic sums of this step
+			log[0] = cnt->macro[0] / 6.0 + cnt->macro[1] + cnt->macro[2];
+			log[1] = cnt->macro[3] + 3.0 * cnt->macro[2];
+			if (kin_in_slot1) {
+				log[2] = cnt->kin[0];
+				log[3] = 0.;
+				log[4] = (double)cnt->kin_n;
+				log[5] = 0.;
+			}
+		}
 	}
 }
 
-void launch_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, double* stage, hipStream_t s, bool overwrite) {
+void launch_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, double* stage, hipStream_t s, bool overwrite,
+						 bool kin_in_slot1, double* log) {
 	if (nblocks == 0) {
 		if (overwrite) launch_clear_macro(cnt, s);
 		return;
 	}
 	hipLaunchKernelGGL(k_force_reduce1, dim3(RED_BLOCKS), dim3(256), 0, s, partials, nblocks, stage);
-	hipLaunchKernelGGL(k_force_reduce2, dim3(1), dim3(RED_BLOCKS), 0, s, cnt, stage, overwrite ? 1 : 0);
+	hipLaunchKernelGGL(k_force_reduce2, dim3(1), dim3(RED_BLOCKS), 0, s, cnt, stage, overwrite ? 1 : 0, kin_in_slot1 ? 1 : 0, log);
 }
 
 }  // namespace ls1

@@ -96,17 +96,20 @@ __device__ __forceinline__ void lj_pair_in(double xi, double yi, double zi, doub
 // updated in place and the NEW position goes to the F arrays (the old positions are still being read by other bricks),
 // from where the next re-binning pass picks it up.  F is never written: -48 B of HBM traffic per molecule and no
 // separate integrator pass.
-__device__ __forceinline__ void lj_store(const ForceParams& P, uint32_t gi, const LjAcc& acc) {
+// Returns m v^2 of the molecule after the post-force kick (the summand of Leapfrog::transition2to3's summv2,
+// integrators/Leapfrog.cpp:115-131 / FullMolecule::upd_postF :382-385), 0 in the unfused mode.
+__device__ __forceinline__ double lj_store(const ForceParams& P, uint32_t gi, const LjAcc& acc) {
 	if (!P.fuse) {
 		P.Fx[gi] = acc.fx;
 		P.Fy[gi] = acc.fy;
 		P.Fz[gi] = acc.fz;
-		return;
+		return 0.;
 	}
 	const double k = P.dt_inv2m;
 	double vx = P.vx[gi] + k * acc.fx;  // upd_postF
 	double vy = P.vy[gi] + k * acc.fy;
 	double vz = P.vz[gi] + k * acc.fz;
+	const double mv2 = P.mass * (vx * vx + vy * vy + vz * vz);
 	vx += k * acc.fx;  // upd_preF
 	vy += k * acc.fy;
 	vz += k * acc.fz;
@@ -116,6 +119,7 @@ __device__ __forceinline__ void lj_store(const ForceParams& P, uint32_t gi, cons
 	P.Fx[gi] = P.x[gi] + P.dt * vx;
 	P.Fy[gi] = P.y[gi] + P.dt * vy;
 	P.Fz[gi] = P.z[gi] + P.dt * vz;
+	return mv2;
 }
 
 __device__ __forceinline__ double wave_sum_lj(double v) {
@@ -145,7 +149,7 @@ __global__ void __launch_bounds__(LTPB * SPLIT, 2 * SPLIT) k_force_lj_brick(Forc
 	__shared__ uint32_t gbeg[NRC];        // global index of the first molecule of every region cell
 	__shared__ uint32_t bstart[NBC + 1];  // prefix over the brick's own cells (i-molecule enumeration)
 	__shared__ uint32_t wsum[NT / 64];
-	__shared__ double red[NT / 64][2];
+	__shared__ double red[NT / 64][3];
 
 	const int tid = threadIdx.x;
 	const BrickSel bs = brick_select<HW, BX, BY, BZ>(P, nbx, nby, nbz);
@@ -195,7 +199,7 @@ __global__ void __launch_bounds__(LTPB * SPLIT, 2 * SPLIT) k_force_lj_brick(Forc
 	const double rc2 = P.rc2, eps24 = P.eps24, sig2 = P.sig2, shift6 = P.shift6;
 	const int half = tid % SPLIT;
 	const int nmy = (NROWS - half + SPLIT - 1) / SPLIT;  // neighbour rows of this lane
-	double u6_tot = 0., vir_tot = 0.;
+	double u6_tot = 0., vir_tot = 0., kin_tot = 0.;
 	for (uint32_t base = 0; base < n_i; base += NT / SPLIT) {  // one pass unless the brick is over-full
 		const uint32_t it = base + (uint32_t)(tid / SPLIT);
 		const bool active = it < n_i;
@@ -314,27 +318,29 @@ __global__ void __launch_bounds__(LTPB * SPLIT, 2 * SPLIT) k_force_lj_brick(Forc
 			acc.fy += __shfl_xor(acc.fy, 1);
 			acc.fz += __shfl_xor(acc.fz, 1);
 		}
-		if (active && half == 0) lj_store(P, gi, acc);
+		if (active && half == 0) kin_tot += lj_store(P, gi, acc);
 		u6_tot += acc.u6;
 		vir_tot += acc.vir;
 	}
 	// every ordered pair contributes half of the pair's U and virial (see kernels_force.hip)
-	double u = wave_sum_lj(0.5 * u6_tot), v = wave_sum_lj(0.5 * vir_tot);
+	double u = wave_sum_lj(0.5 * u6_tot), v = wave_sum_lj(0.5 * vir_tot), kn = wave_sum_lj(kin_tot);
 	const int lane = tid & 63, w = tid >> 6;
 	if (lane == 0) {
 		red[w][0] = u;
 		red[w][1] = v;
+		red[w][2] = kn;
 	}
 	__syncthreads();
 	if (tid == 0) {
 		double* out = P.partials + (size_t)blockIdx.x * 4;
-		double su = 0., sv = 0.;
+		double su = 0., sv = 0., sk = 0.;
 		for (int i = 0; i < NT / 64; ++i) {
 			su += red[i][0];
 			sv += red[i][1];
+			sk += red[i][2];
 		}
 		out[0] = su;
-		out[1] = 0.;
+		out[1] = sk;  // fused mode: sum m v^2 of the brick's molecules (the uX slot is unused by single-centre LJ)
 		out[2] = 0.;
 		out[3] = sv;
 	}
@@ -411,7 +417,7 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 	__shared__ uint32_t cstart[NRC + 1];
 	__shared__ uint32_t gbeg[NRC];
 	__shared__ uint32_t wsum[NW];
-	__shared__ double red[NW][2];
+	__shared__ double red[NW][3];
 
 	const int tid = threadIdx.x;
 	const BrickSel bs = brick_select<HW, BX, BY, BZ>(P, nbx, nby, nbz);
@@ -482,7 +488,7 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 	auto count_hit = [](uint32_t& cnt, float d, float thr) {
 		asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(cnt) : "v"(d), "v"(thr) : "vcc");
 	};
-	double u6_tot = 0., vir_tot = 0.;
+	double u6_tot = 0., vir_tot = 0., kin_tot = 0.;
 
 	for (int cc = 0; cc < NBC / NW; ++cc) {              // every wave owns NBC/NW cells of the brick
 		const int c = wv * (NBC / NW) + cc;
@@ -612,26 +618,28 @@ __global__ void __launch_bounds__(NT, NT / 128) k_force_lj_mfma(ForceParams P, i
 			acc.fx += __shfl_xor(acc.fx, 32);
 			acc.fy += __shfl_xor(acc.fy, 32);
 			acc.fz += __shfl_xor(acc.fz, 32);
-			if (valid && grp == 0) lj_store(P, gi, acc);
+			if (valid && grp == 0) kin_tot += lj_store(P, gi, acc);
 			u6_tot += acc.u6;
 			vir_tot += acc.vir;
 		}
 	}
-	double u = wave_sum_lj(0.5 * u6_tot), v = wave_sum_lj(0.5 * vir_tot);
+	double u = wave_sum_lj(0.5 * u6_tot), v = wave_sum_lj(0.5 * vir_tot), kn = wave_sum_lj(kin_tot);
 	if (lane == 0) {
 		red[wv][0] = u;
 		red[wv][1] = v;
+		red[wv][2] = kn;
 	}
 	__syncthreads();
 	if (tid == 0) {
 		double* out = P.partials + (size_t)blockIdx.x * 4;
-		double su = 0., sv = 0.;
+		double su = 0., sv = 0., sk = 0.;
 		for (int i = 0; i < NW; ++i) {
 			su += red[i][0];
 			sv += red[i][1];
+			sk += red[i][2];
 		}
 		out[0] = su;
-		out[1] = 0.;
+		out[1] = sk;  // fused mode: sum m v^2 (see k_force_lj_brick)
 		out[2] = 0.;
 		out[3] = sv;
 	}

@@ -189,7 +189,8 @@ void launch_kick(const IntegArgs& a, hipStream_t s, uint32_t* nblocks) {
 	else hipLaunchKernelGGL(k_kick<false>, dim3(nb), dim3(ITPB), 0, s, a);
 }
 
-__global__ void __launch_bounds__(256) k_kin_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, double target_T) {
+__global__ void __launch_bounds__(256) k_kin_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, double target_T,
+													 double* log) {
 	double v[3] = {0., 0., 0.};
 	for (uint32_t b = threadIdx.x; b < nblocks; b += 256)
 		for (int k = 0; k < 3; ++k) v[k] += partials[(size_t)b * 4 + k];
@@ -212,6 +213,12 @@ __global__ void __launch_bounds__(256) k_kin_reduce(DevCounters* cnt, const doub
 		}
 		cnt->beta[0] = bt;
 		cnt->beta[1] = br;
+		if (log) {
+			log[2] = cnt->kin[0];
+			log[3] = cnt->kin[1];
+			log[4] = (double)cnt->kin_n;
+			log[5] = (double)cnt->kin_rotdof;
+		}
 	}
 }
 
@@ -241,9 +248,9 @@ void launch_scale(const IntegArgs& a, double beta_trans, double beta_rot, bool f
 	else hipLaunchKernelGGL(k_scale<false>, grid, dim3(ITPB), 0, s, a, beta_trans, beta_rot, from_device);
 }
 
-void launch_kin_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, hipStream_t s, double target_T) {
+void launch_kin_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, hipStream_t s, double target_T, double* log) {
 	if (nblocks == 0) return;
-	hipLaunchKernelGGL(k_kin_reduce, dim3(1), dim3(256), 0, s, cnt, partials, nblocks, target_T);
+	hipLaunchKernelGGL(k_kin_reduce, dim3(1), dim3(256), 0, s, cnt, partials, nblocks, target_T, log);
 }
 
 }  // namespace ls1

@@ -340,32 +340,43 @@ class DistributedSimulation:
                     rot_dof=int(v[5]))
 
 
-def build_weak_scaling_box(comps, rc, n_per_dim, world, rank, local_rank, bcc_box, cic=None, kernel=0,
-                           stage_through_host=False, loopback=False):
-    """bench.py helper: every rank owns a 2*n^3 jittered bcc block; the global box is the rank grid of such blocks."""
+def build_strong_scaling_box(comps, rc, n_per_dim, world, rank, local_rank, rho, temp, cic=None, kernel=0,
+                             stage_through_host=False, loopback=False, options=None):
+    """bench.py helper: the GLOBAL jittered bcc liquid of 2*n^3 molecules (synth.py) split over the rank grid; every
+    rank generates exactly the molecules of its own sub-box, in device memory, chunk by chunk."""
     import torch
     import torch.distributed as dist
 
+    from . import synth
     from .engine import DeviceEngine
 
     grid = dims_create(world)
-    Ls, r, v = bcc_box(n_per_dim, seed=1234 + rank)
-    global_len = np.array([Ls * g for g in grid])
+    L = synth.box_length(n_per_dim, rho)
+    global_len = np.array([L, L, L])
     dc = CartesianDecomposition(world, rank, global_len, grid, loopback=loopback)
     lo, hi = dc.bounding_box()
-    r = r + lo
-    for d in range(3):  # numerical safety: stay strictly inside the own sub-box
-        r[:, d] = np.clip(r[:, d], lo[d], np.nextafter(hi[d], lo[d]))
     eng = DeviceEngine(local_rank)
     eng.set_components(comps, rc)
     if cic:
         eng.set_option("cells_in_cutoff", cic)
     eng.set_option("force_kernel", kernel)
+    for k, v in (options or {}).items():
+        eng.set_option(k, v)
     eng.set_domain(global_len, lo, hi, rank, dc.neighbor_table())
-    n = len(r)
-    ids = np.arange(1, n + 1, dtype=np.uint64) + np.uint64(rank) * np.uint64(n)
-    eng.upload(ids, np.zeros(n, np.int32), r, v)
-    sim = DistributedSimulation(dc, eng, dist, torch.device("cuda", local_rank), stage_through_host=stage_through_host)
-    sim.n_global = n * world
+    dev = torch.device("cuda", local_rank)
+    # upper bound of the sub-box population (uniform density + the jitter band on every face)
+    vol = float(np.prod(hi - lo + 0.2))
+    eng.upload_begin(int(vol * rho * 1.02) + 4096)
+    for ids_t, r_t, v_t in synth.bcc_chunks_device(torch, dev, n_per_dim, lo, hi, rho=rho, temp=temp):
+        torch.cuda.synchronize()
+        eng.upload_chunk_device(ids_t.numel(), ids_t.data_ptr(), 0, r_t.data_ptr(), v_t.data_ptr())
+    eng.upload_end()
+    torch.cuda.empty_cache()
+    sim = DistributedSimulation(dc, eng, dist, dev, stage_through_host=stage_through_host)
+    n_mine = torch.tensor([eng.count()[0]], dtype=torch.int64, device="cpu" if stage_through_host else dev)
+    if world > 1:
+        dist.all_reduce(n_mine)
+    sim.n_global = int(n_mine.item())
+    assert sim.n_global == 2 * n_per_dim ** 3, (sim.n_global, 2 * n_per_dim ** 3)
     sim.initial_forces()
     return sim

@@ -98,6 +98,47 @@ class DeviceEngine:
         self._chk(self.lib.ls1hip_upload(self.ctx, n, ids.ctypes.data_as(capi._u64p), cid.ctypes.data_as(capi._i32p),
                                          capi.dptr(r), capi.dptr(v), capi.dptr(q), capi.dptr(D)))
 
+    def upload_begin(self, n_total: int):
+        """Streaming upload: begin -> any number of upload_chunk / upload_records -> upload_end."""
+        self._chk(self.lib.ls1hip_upload_begin(self.ctx, int(n_total)))
+
+    def upload_chunk(self, ids, cid, r, v, q=None, D=None):
+        n = len(ids)
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        cid = np.ascontiguousarray(cid, dtype=np.int32) if cid is not None else None
+        r = capi.f64(r, (n, 3)); v = capi.f64(v, (n, 3))
+        q = capi.f64(q, (n, 4)) if q is not None else None
+        D = capi.f64(D, (n, 3)) if D is not None else None
+        self._chk(self.lib.ls1hip_upload_chunk(self.ctx, n, ids.ctypes.data_as(capi._u64p),
+                                               cid.ctypes.data_as(capi._i32p) if cid is not None else None,
+                                               capi.dptr(r), capi.dptr(v), capi.dptr(q), capi.dptr(D)))
+
+    def upload_chunk_device(self, n: int, id_ptr: int, cid_ptr: int, r_ptr: int, v_ptr: int, q_ptr: int = 0, D_ptr: int = 0):
+        """Chunk that already lives in device memory (AoS arrays: id u64/i64 [n], cid i32 [n] or 0, r [n,3], v [n,3], ...)."""
+        vp = lambda p: C.c_void_p(p) if p else None  # noqa: E731
+        self._chk(self.lib.ls1hip_upload_chunk_device(self.ctx, int(n), vp(id_ptr), vp(cid_ptr), vp(r_ptr), vp(v_ptr),
+                                                      vp(q_ptr), vp(D_ptr)))
+
+    def upload_records(self, records, fmt: int = capi.REC_ICRVQD):
+        """records: bytes-like / uint8 array of packed checkpoint records (116 / 60 / 56 bytes each)."""
+        buf = np.frombuffer(records, dtype=np.uint8) if not isinstance(records, np.ndarray) else records.view(np.uint8).reshape(-1)
+        buf = np.ascontiguousarray(buf)
+        rb = capi.REC_BYTES[fmt]
+        if buf.size % rb:
+            raise ValueError(f"record buffer of {buf.size} bytes is not a multiple of {rb}")
+        self._chk(self.lib.ls1hip_upload_records(self.ctx, buf.size // rb, C.c_void_p(buf.ctypes.data), int(fmt)))
+
+    def upload_end(self):
+        self._chk(self.lib.ls1hip_upload_end(self.ctx))
+
+    def download_records(self, first: int = 0, n: int | None = None):
+        """Owned molecules [first, first+n) as packed ICRVQD records (uint8 array of n*116 bytes)."""
+        if n is None:
+            n = self.count()[0] - first
+        out = np.zeros(n * 116, dtype=np.uint8)
+        self._chk(self.lib.ls1hip_download_records(self.ctx, int(first), int(n), C.c_void_p(out.ctypes.data)))
+        return out
+
     def count(self):
         a = C.c_size_t(); b = C.c_size_t()
         self._chk(self.lib.ls1hip_count(self.ctx, C.byref(a), C.byref(b)))
@@ -111,6 +152,19 @@ class DeviceEngine:
                                                  cid.ctypes.data_as(capi._i32p), capi.dptr(r), capi.dptr(v),
                                                  capi.dptr(q), capi.dptr(D)))
         return dict(ids=ids, cid=cid, r=r, v=v, q=q, D=D)
+
+    def download_ids(self):
+        """Molecule ids only (device order) — the cheap survival check at sizes where a full download is 10 GB."""
+        n, _ = self.count()
+        ids = np.zeros(n, dtype=np.uint64)
+        self._chk(self.lib.ls1hip_download_state(self.ctx, n, ids.ctypes.data_as(capi._u64p), None, None, None, None, None))
+        return ids
+
+    def download_velocities(self):
+        n, _ = self.count()
+        v = np.zeros((n, 3))
+        self._chk(self.lib.ls1hip_download_state(self.ctx, n, None, None, None, capi.dptr(v), None, None))
+        return v
 
     def download_forces(self, with_vi: bool = False):
         n, _ = self.count()
@@ -177,6 +231,15 @@ class DeviceEngine:
         out = np.zeros(6)
         self._chk(self.lib.ls1hip_run(self.ctx, float(dt), int(nsteps), capi.dptr(out)))
         return dict(upot=out[0], virial=out[1], summv2=out[2], sumIw2=out[3], n=int(out[4]), rot_dof=int(out[5]))
+
+    def run_log(self):
+        """[nsteps, 6] per-step globals {upot, virial, summv2, sumIw2, N, rotDOF} of the last run (NaN = not computed)."""
+        n = C.c_size_t()
+        self._chk(self.lib.ls1hip_run_log(self.ctx, 0, None, C.byref(n)))
+        out = np.zeros((n.value, 6))
+        if n.value:
+            self._chk(self.lib.ls1hip_run_log(self.ctx, n.value, capi.dptr(out), C.byref(n)))
+        return out
 
     # -- multi-GPU plumbing -----------------------------------------------------------------------------------------
     def export_counts(self, kind: int):

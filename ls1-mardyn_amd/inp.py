@@ -275,37 +275,83 @@ CHECKPOINT_RECORD = np.dtype([("id", "<u8"), ("cid", "<u4"), ("r", "<f8", 3), ("
 assert CHECKPOINT_RECORD.itemsize == 116
 
 
-def read_checkpoint(prefix: str, components: ComponentSet | None = None) -> PhaseSpace:
-    """Read `<prefix>.header.xml` + `<prefix>.dat`.  The component set is not part of a binary checkpoint (the
-    reference takes it from the XML config), so it is passed in."""
+# the two short record layouts BinaryReader also accepts (io/BinaryReader.cpp:103-108,179-213): no orientation / angular
+# momentum on disk (q = (1,0,0,0), D = 0) and, for IRV, no component id (component 1)
+CHECKPOINT_RECORD_ICRV = np.dtype([("id", "<u8"), ("cid", "<u4"), ("r", "<f8", 3), ("v", "<f8", 3)])
+CHECKPOINT_RECORD_IRV = np.dtype([("id", "<u8"), ("r", "<f8", 3), ("v", "<f8", 3)])
+assert CHECKPOINT_RECORD_ICRV.itemsize == 60 and CHECKPOINT_RECORD_IRV.itemsize == 56
+CHECKPOINT_FORMATS = {"ICRVQD": (0, CHECKPOINT_RECORD), "ICRV": (1, CHECKPOINT_RECORD_ICRV), "IRV": (2, CHECKPOINT_RECORD_IRV)}
+
+
+def read_checkpoint_header(prefix: str) -> dict:
+    """`<prefix>.header.xml` (Domain::writeCheckpointHeaderXML, Domain.cpp:572-595): time, box, molecule count, format."""
     import xml.etree.ElementTree as ET
 
     hdr = ET.parse(prefix + ".header.xml").getroot().find("headerinfo")
-    time = float(hdr.findtext("time"))
     ln = hdr.find("length")
-    length = np.array([float(ln.findtext(k)) for k in ("x", "y", "z")])
-    n = int(hdr.findtext("number"))
     fmt = hdr.find("format").get("type")
-    if fmt != "ICRVQD":
+    if fmt not in CHECKPOINT_FORMATS:
         raise ValueError(f"unsupported binary molecule format {fmt!r}")
-    rec = np.fromfile(prefix + ".dat", dtype=CHECKPOINT_RECORD)
+    return dict(time=float(hdr.findtext("time")), length=np.array([float(ln.findtext(k)) for k in ("x", "y", "z")]),
+                number=int(hdr.findtext("number")), format=fmt, format_code=CHECKPOINT_FORMATS[fmt][0],
+                record_bytes=CHECKPOINT_FORMATS[fmt][1].itemsize)
+
+
+def read_checkpoint(prefix: str, components: ComponentSet | None = None) -> PhaseSpace:
+    """Read `<prefix>.header.xml` + `<prefix>.dat`.  The component set is not part of a binary checkpoint (the
+    reference takes it from the XML config), so it is passed in."""
+    h = read_checkpoint_header(prefix)
+    n = h["number"]
+    rec = np.fromfile(prefix + ".dat", dtype=CHECKPOINT_FORMATS[h["format"]][1])
     if len(rec) != n:
         raise ValueError(f"{prefix}.dat holds {len(rec)} records, header says {n}")
     comps = components if components is not None else ComponentSet([], np.zeros((0, 2)), 0.0)
-    return PhaseSpace(comps, length, rec["id"].astype(np.uint64), rec["cid"].astype(np.int32) - 1,
-                      np.ascontiguousarray(rec["r"]), np.ascontiguousarray(rec["v"]), np.ascontiguousarray(rec["q"]),
-                      np.ascontiguousarray(rec["D"]), time, 0.0)
+    cid = rec["cid"].astype(np.int32) - 1 if "cid" in rec.dtype.names else np.zeros(n, np.int32)
+    q = np.ascontiguousarray(rec["q"]) if "q" in rec.dtype.names else np.tile([1.0, 0.0, 0.0, 0.0], (n, 1))
+    D = np.ascontiguousarray(rec["D"]) if "D" in rec.dtype.names else np.zeros((n, 3))
+    return PhaseSpace(comps, h["length"], rec["id"].astype(np.uint64), cid, np.ascontiguousarray(rec["r"]),
+                      np.ascontiguousarray(rec["v"]), q, D, h["time"], 0.0)
+
+
+def stream_checkpoint(prefix: str, engine, chunk: int = 1 << 22) -> dict:
+    """Device-side ingest of a binary checkpoint: the record bytes go from the (memory-mapped) file to
+    the GPU chunk by chunk and are unpacked there (ls1hip_upload_records) — no host-side molecule arrays, whatever
+    the size.  The engine's components and domain must be set.  Returns the header."""
+    h = read_checkpoint_header(prefix)
+    n, rb = h["number"], h["record_bytes"]
+    raw = np.memmap(prefix + ".dat", dtype=np.uint8, mode="r")
+    if raw.size != n * rb:
+        raise ValueError(f"{prefix}.dat holds {raw.size} bytes, header says {n} x {rb}")
+    engine.upload_begin(n)
+    for o in range(0, n, chunk):
+        m = min(chunk, n - o)
+        engine.upload_records(np.ascontiguousarray(raw[o * rb:(o + m) * rb]), h["format_code"])
+    engine.upload_end()
+    return h
+
+
+def write_checkpoint_from_engine(prefix: str, engine, length, time: float = 0.0, chunk: int = 1 << 22) -> None:
+    """The reverse path: ICRVQD records are packed on the device (ls1hip_download_records) and appended to the file."""
+    n = engine.count()[0]
+    _write_checkpoint_header(prefix, n, length, time)
+    with open(prefix + ".dat", "wb") as fh:
+        for o in range(0, n, chunk):
+            engine.download_records(o, min(chunk, n - o)).tofile(fh)
+
+
+def _write_checkpoint_header(prefix: str, n: int, length, time: float) -> None:
+    e = lambda x: f"{float(x):21.15e}"  # FORMAT_SCI_MAX_DIGITS_WIDTH_21  # noqa: E731
+    with open(prefix + ".header.xml", "w") as fh:
+        fh.write("<?xml version='1.0' encoding='UTF-8'?>\n<mardyn version=\"20100525\" >\n\t<headerinfo>\n")
+        fh.write(f"\t\t<time>{e(time)}</time>\n\t\t<length>\n")
+        fh.write(f"\t\t\t<x>{e(length[0])}</x> <y>{e(length[1])}</y> <z>{e(length[2])}</z>\n")
+        fh.write(f"\t\t</length>\n\t\t<number>{n}</number>\n\t\t<format type=\"ICRVQD\"/>\n\t</headerinfo>\n</mardyn>\n")
 
 
 def write_checkpoint(prefix: str, ps: PhaseSpace) -> None:
     """Write the reference's binary checkpoint pair (same header text layout, same record bytes)."""
     n = len(ps.ids)
-    e = lambda x: f"{float(x):21.15e}"  # FORMAT_SCI_MAX_DIGITS_WIDTH_21  # noqa: E731
-    with open(prefix + ".header.xml", "w") as fh:
-        fh.write("<?xml version='1.0' encoding='UTF-8'?>\n<mardyn version=\"20100525\" >\n\t<headerinfo>\n")
-        fh.write(f"\t\t<time>{e(ps.time)}</time>\n\t\t<length>\n")
-        fh.write(f"\t\t\t<x>{e(ps.length[0])}</x> <y>{e(ps.length[1])}</y> <z>{e(ps.length[2])}</z>\n")
-        fh.write(f"\t\t</length>\n\t\t<number>{n}</number>\n\t\t<format type=\"ICRVQD\"/>\n\t</headerinfo>\n</mardyn>\n")
+    _write_checkpoint_header(prefix, n, ps.length, ps.time)
     rec = np.zeros(n, dtype=CHECKPOINT_RECORD)
     rec["id"] = ps.ids
     rec["cid"] = np.asarray(ps.cid, dtype=np.uint32) + 1

@@ -1,0 +1,161 @@
+"""Synthetic phase spaces for benchmarks and full-size tests: the bcc start lattice of the reference's
+CubicGridGenerator (two interleaved simple-cubic grids, ParticleCellBase::initCubicGrid,
+/root/reference/src/particleContainer/ParticleCellBase.cpp:73-177; molecules per dimension from
+CubicGridGeneratorInternal::determineMolsPerDimension, io/CubicGridGeneratorInternal.cpp:124-186) with the
+deterministic per-molecule displacement SURVEY.md 8(d)-2 prescribes (0.1 sigma * (u - 1/2), u = splitmix64 of the
+molecule id) and Maxwell velocities drawn from the same hash.
+
+Every quantity is a pure function of the GLOBAL molecule id, so any rank can generate exactly its own sub-box of the
+same global liquid (strong scaling) in bounded chunks, on the host (numpy) or directly in device memory (torch) —
+a 10^8-molecule start configuration never exists as one host array.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+RHO_DEFAULT = 0.785302672  # examples/Generators/cubic_grid_generator/config.xml:43
+_M64 = (1 << 64) - 1
+_G, _C1, _C2 = 0x9E3779B97F4A7C15, 0xBF58476D1CE4E5B9, 0x94D049BB133111EB
+
+
+def box_length(n_per_dim: int, rho: float = RHO_DEFAULT) -> float:
+    return (2 * n_per_dim ** 3 / rho) ** (1.0 / 3.0)
+
+
+# ---- numpy -------------------------------------------------------------------------------------------------------
+def _splitmix_np(x):
+    with np.errstate(over="ignore"):
+        z = x + np.uint64(_G)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(_C1)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(_C2)
+        return z ^ (z >> np.uint64(31))
+
+
+def _unit_np(h):
+    return (h >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def _site_block_np(ix, iy, iz, n, L, jitter, temp):
+    """molecules of the lattice cells (ix, iy, iz) (flat index arrays): both bcc sites each"""
+    a = L / n
+    cell = (iz.astype(np.uint64) * np.uint64(n) + iy.astype(np.uint64)) * np.uint64(n) + ix.astype(np.uint64)
+    out = []
+    for s, off in ((0, 0.25), (1, 0.75)):
+        ids = cell * np.uint64(2) + np.uint64(s + 1)
+        base = np.stack([(ix + off) * a, (iy + off) * a, (iz + off) * a], axis=1)
+        with np.errstate(over="ignore"):
+            u = np.stack([_unit_np(_splitmix_np(ids * np.uint64(16) + np.uint64(k))) for k in range(3)], axis=1)
+            w = [_unit_np(_splitmix_np(ids * np.uint64(16) + np.uint64(4 + k))) for k in range(4)]
+        r = base + jitter * (u - 0.5)
+        r = np.mod(r, L)
+        r[r >= L] = 0.0
+        # Box-Muller: two pairs of uniforms -> three normals
+        m0 = np.sqrt(-2.0 * np.log(1.0 - w[0]))
+        m1 = np.sqrt(-2.0 * np.log(1.0 - w[2]))
+        v = np.stack([m0 * np.cos(2 * np.pi * w[1]), m0 * np.sin(2 * np.pi * w[1]), m1 * np.cos(2 * np.pi * w[3])], axis=1)
+        out.append((ids, r, v * np.sqrt(temp)))
+    return out
+
+
+def _index_ranges(n, L, lo, hi, jitter):
+    """per dimension: lattice cell indices whose (displaced, wrapped) sites can fall into [lo, hi)"""
+    a = L / n
+    rng = []
+    for d in range(3):
+        if lo[d] <= 0.0 and hi[d] >= L:
+            rng.append(np.arange(n, dtype=np.int64))
+            continue
+        i0 = int(np.floor((lo[d] - jitter) / a - 0.75)) - 1
+        i1 = int(np.ceil((hi[d] + jitter) / a)) + 1
+        if i1 - i0 >= n:
+            rng.append(np.arange(n, dtype=np.int64))
+        else:
+            rng.append(np.mod(np.arange(i0, i1, dtype=np.int64), n))
+    return rng
+
+
+def bcc_chunks(n_per_dim: int, lo=None, hi=None, rho: float = RHO_DEFAULT, temp: float = 0.95, jitter: float = 0.1,
+               chunk: int = 1 << 21):
+    """Yield (ids uint64, r [m,3], v [m,3]) chunks of the global jittered bcc liquid restricted to the sub-box
+    [lo, hi) (default: the whole box).  Every global molecule is produced by exactly one disjoint sub-box."""
+    n = int(n_per_dim)
+    L = box_length(n, rho)
+    lo = np.zeros(3) if lo is None else np.asarray(lo, dtype=np.float64)
+    hi = np.full(3, L) if hi is None else np.asarray(hi, dtype=np.float64)
+    rx, ry, rz = _index_ranges(n, L, lo, hi, jitter)
+    per_plane = len(rx) * len(ry) * 2
+    planes = max(1, chunk // max(per_plane, 1))
+    for z0 in range(0, len(rz), planes):
+        zz = rz[z0:z0 + planes]
+        iz, iy, ix = np.meshgrid(zz, ry, rx, indexing="ij")
+        for ids, r, v in _site_block_np(ix.ravel(), iy.ravel(), iz.ravel(), n, L, jitter, temp):
+            keep = np.all((r >= lo) & (r < hi), axis=1)
+            if keep.all():
+                yield ids, r, v
+            elif keep.any():
+                yield ids[keep], r[keep], v[keep]
+
+
+def bcc_box(n_per_dim: int, **kw):
+    """whole box in one piece (small sizes: tests, CPU comparisons)"""
+    parts = list(bcc_chunks(n_per_dim, **kw))
+    ids = np.concatenate([p[0] for p in parts])
+    r = np.concatenate([p[1] for p in parts])
+    v = np.concatenate([p[2] for p in parts])
+    return box_length(n_per_dim, kw.get("rho", RHO_DEFAULT)), ids, r, v
+
+
+# ---- torch (device-resident generation; same arithmetic in two's-complement int64) --------------------------------
+def _s64(x):
+    x &= _M64
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+def _lsr(z, k):
+    return (z >> k) & ((1 << (64 - k)) - 1)
+
+
+def _splitmix_t(x):
+    z = x + _s64(_G)
+    z = (z ^ _lsr(z, 30)) * _s64(_C1)
+    z = (z ^ _lsr(z, 27)) * _s64(_C2)
+    return z ^ _lsr(z, 31)
+
+
+def bcc_chunks_device(torch, device, n_per_dim: int, lo=None, hi=None, rho: float = RHO_DEFAULT, temp: float = 0.95,
+                      jitter: float = 0.1, chunk: int = 1 << 22):
+    """Same liquid as bcc_chunks, generated in device memory: yields (ids int64, r [m,3] f64, v [m,3] f64) tensors."""
+    n = int(n_per_dim)
+    L = box_length(n, rho)
+    a = L / n
+    lo_h = np.zeros(3) if lo is None else np.asarray(lo, dtype=np.float64)
+    hi_h = np.full(3, L) if hi is None else np.asarray(hi, dtype=np.float64)
+    rx, ry, rz = (torch.from_numpy(x).to(device) for x in _index_ranges(n, L, lo_h, hi_h, jitter))
+    lo_t = torch.tensor(lo_h, dtype=torch.float64, device=device)
+    hi_t = torch.tensor(hi_h, dtype=torch.float64, device=device)
+    per_plane = len(rx) * len(ry) * 2
+    planes = max(1, chunk // max(per_plane, 1))
+    two_pi = 2.0 * np.pi
+    for z0 in range(0, len(rz), planes):
+        zz = rz[z0:z0 + planes]
+        iz, iy, ix = torch.meshgrid(zz, ry, rx, indexing="ij")
+        ix, iy, iz = ix.reshape(-1), iy.reshape(-1), iz.reshape(-1)
+        cell = (iz * n + iy) * n + ix
+        for s, off in ((0, 0.25), (1, 0.75)):
+            ids = cell * 2 + (s + 1)
+            base = torch.stack([(ix.double() + off) * a, (iy.double() + off) * a, (iz.double() + off) * a], dim=1)
+            unit = lambda k: _lsr(_splitmix_t(ids * 16 + k), 11).double() * (1.0 / 9007199254740992.0)  # noqa: E731
+            u = torch.stack([unit(0), unit(1), unit(2)], dim=1)
+            r = base + jitter * (u - 0.5)
+            r = torch.remainder(r, L)
+            r[r >= L] = 0.0
+            w0, w1, w2, w3 = unit(4), unit(5), unit(6), unit(7)
+            m0 = torch.sqrt(-2.0 * torch.log(1.0 - w0))
+            m1 = torch.sqrt(-2.0 * torch.log(1.0 - w2))
+            v = torch.stack([m0 * torch.cos(two_pi * w1), m0 * torch.sin(two_pi * w1), m1 * torch.cos(two_pi * w3)], dim=1)
+            v = v * float(np.sqrt(temp))
+            keep = ((r >= lo_t) & (r < hi_t)).all(dim=1)
+            if not bool(keep.all()):
+                ids, r, v = ids[keep], r[keep], v[keep]
+            if ids.numel():
+                yield ids.contiguous(), r.contiguous(), v.contiguous()

@@ -72,3 +72,15 @@ def rel_max(a, b, floor=0.0):
     if den == 0.0:
         return float(np.max(np.abs(a - b))) if np.size(a) else 0.0
     return float(np.max(np.abs(a - b)) / den)
+
+
+def rel_componentwise(a, b, floor_frac=1e-3):
+    """max over components with |b| > floor_frac * max|b| of |a-b| / |b|: catches a small force that is relatively wrong
+    while the max-norm metric (rel_max) still passes.  Components below the floor are cancellation residues."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    if not b.size:
+        return 0.0
+    big = np.abs(b) > floor_frac * np.max(np.abs(b))
+    if not np.any(big):
+        return 0.0
+    return float(np.max(np.abs(a - b)[big] / np.abs(b)[big]))

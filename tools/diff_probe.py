@@ -7,7 +7,7 @@ inp = importlib.import_module("ls1-mardyn_amd.inp")
 capi = importlib.import_module("ls1-mardyn_amd.capi")
 engine_mod = importlib.import_module("ls1-mardyn_amd.engine")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 171
-L, r, v = bench.bcc_box(n)
+L, _ids, r, v = __import__("importlib").import_module("ls1-mardyn_amd.synth").bcc_box(n)
 eng = engine_mod.DeviceEngine(0)
 eng.set_components(bench.lj_components(inp), bench.RC)
 eng.set_domain([L, L, L])

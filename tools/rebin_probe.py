@@ -6,7 +6,7 @@ import bench
 inp = importlib.import_module("ls1-mardyn_amd.inp")
 engine_mod = importlib.import_module("ls1-mardyn_amd.engine")
 import torch
-L, r, v = bench.bcc_box(171)
+L, _ids, r, v = __import__("importlib").import_module("ls1-mardyn_amd.synth").bcc_box(171)
 N = len(r)
 for det in (1, 0):
     eng = engine_mod.DeviceEngine(0)

@@ -8,7 +8,7 @@ inp = importlib.import_module("ls1-mardyn_amd.inp")
 engine_mod = importlib.import_module("ls1-mardyn_amd.engine")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
-L, r, v = bench.bcc_box(n)
+L, _ids, r, v = __import__("importlib").import_module("ls1-mardyn_amd.synth").bcc_box(n)
 N = len(r)
 e = engine_mod.DeviceEngine(0)
 shifted = int(os.environ.get("LS1_SOAK_SHIFTED", "0"))  # 1: truncated AND shifted LJ (U continuous at r_c)

@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--cic", type=int, default=0, help="cells in cutoff (0 = engine default)")
     ap.add_argument("--split", type=int, default=0, help="lanes per molecule in the LDS LJ kernel (0 = engine default)")
     ap.add_argument("--overlap", type=int, default=-1, help="ls1hip_run halo mode: 0 single pass, 1 overlapped, 2 split sequential")
+    ap.add_argument("--skin", type=float, default=0.3,
+                    help="neighbour-list skin in sigma (list-reuse loop of ls1hip_run, single GPU); 0 = per-step search kernels")
     ap.add_argument("--no-fuse", action="store_true", help="separate integrator passes instead of the fused force pass")
     ap.add_argument("--decomp", action="store_true",
                     help="diagnostic: run the decomposed (multi-rank) step loop even with one rank")
@@ -193,6 +195,8 @@ def main():
         if args.cic:
             eng.set_option("cells_in_cutoff", args.cic)
         eng.set_option("force_kernel", args.kernel)
+        if args.skin > 0 and not args.no_fuse and args.kernel != 1 and args.cic in (0, 1):
+            eng.set_verlet(args.skin)
         if args.split:
             eng.set_option("lj_split", args.split)
         eng.set_domain([L, L, L])
@@ -291,6 +295,11 @@ def main():
                                    f"forces, kick) with per-step U_pot / virial / sum mv^2, FP64",
                        "molecules_per_gpu": n_local, "decomposition": getattr(sim, "grid_desc", "single GPU, periodic images local"),
                        "force_kernel": e.get_option("force_kernel"), "cells_in_cutoff": e.get_option("cells_in_cutoff"),
+                       "neighbour_lists": ({"skin": args.skin, "list_builds": e.get_option("verlet_builds"),
+                                            "list_steps": e.get_option("verlet_steps"),
+                                            "note": "lists, binning and halo slots reused until the device-side displacement "
+                                                    "bound exceeds skin/2 (counts since start incl. warm-up and profiling steps)"}
+                                           if e.get_option("verlet_lists") else None),
                        "integration": ("fused into the force pass between steps (reduced-memory mode), last step separate"
                                        if fused_on else "separate integrator passes")},
             "roofline": {"bound": "hbm", "kernel": "pair-force traversal (k_force_*)", "achieved": achieved,

@@ -224,6 +224,17 @@ int ls1hip_set_thermostat(ls1hip_ctx* ctx, int enabled, double target_temperatur
 int ls1hip_long_range_homogeneous(ls1hip_ctx* ctx, const uint64_t* n_per_component, double global_rho,
 								  double* upot_corr, double* virial_corr);
 
+/* Neighbour-list reuse for ls1hip_run (single-centre LJ fast path, single rank, one cell per cutoff): the cell grid, the
+ * halo shell and per-molecule neighbour lists are built with rc + skin and kept for as many steps as no molecule can have
+ * moved by more than skin / 2 — the fused force pass reports max |v| of every step, the device accumulates the
+ * displacement bound sum(dt * vmax) and ls1hip_run re-bins / rebuilds exactly when it exceeds skin / 2 (no guessed
+ * interval; forces, U_pot and virial are the per-step kernels' to rounding, every listed pair is re-tested against rc in
+ * FP64).  Between rebuilds there is no search, no re-binning and no halo regeneration.  Must be called after
+ * ls1hip_set_components and before ls1hip_set_domain.  Positions reported by the download calls are wrapped into the box.
+ * Precedent in the reference: the Verlet-list containers behind particleContainer/AutoPasContainer.cpp:281-346
+ * (verletSkinRadius / verletRebuildFrequency).  Read-only options "verlet_lists", "verlet_builds", "verlet_steps". */
+int ls1hip_set_verlet(ls1hip_ctx* ctx, int enabled, double skin);
+
 /* nsteps full time steps entirely on the device (single rank, all directions local), no host round trip
  * inside: the loop body of Simulation::simulate (Simulation.cpp:979-1167) for an NVE run without plugins.
  * out6 (may be NULL) = {upot, virial, summv2, sumIw2, N, rotDOF} of the LAST step. */

@@ -53,6 +53,7 @@ SYMBOLS = {
     "ls1hip_scale_velocities": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "ls1hip_set_thermostat": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     "ls1hip_long_range_homogeneous": (C.c_int, [C.c_void_p, _u64p, C.c_double, _dp, _dp]),
+    "ls1hip_set_verlet": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     "ls1hip_run": (C.c_int, [C.c_void_p, C.c_double, C.c_ulong, _dp]),
     "ls1hip_run_log": (C.c_int, [C.c_void_p, C.c_size_t, _dp, C.POINTER(C.c_size_t)]),
     "ls1hip_export_counts": (C.c_int, [C.c_void_p, C.c_int, _u64p]),

@@ -96,7 +96,13 @@ static void free_mol(ls1hip_ctx* c) {
 	dfree(f.Fx); dfree(f.Fy); dfree(f.Fz); dfree(f.Mx); dfree(f.My); dfree(f.Mz); dfree(f.Vix); dfree(f.Viy); dfree(f.Viz);
 	HaloStage& h = c->hs;
 	dfree(h.x); dfree(h.y); dfree(h.z); dfree(h.q0); dfree(h.q1); dfree(h.q2); dfree(h.q3); dfree(h.id); dfree(h.cid);
-	dfree(h.key); dfree(h.rank);
+	dfree(h.key); dfree(h.rank); dfree(h.src); dfree(h.dir);
+	dfree(c->d_halo_src); dfree(c->d_halo_dir);
+	dfree(c->alt_x); dfree(c->alt_y); dfree(c->alt_z);
+	dfree(c->d_vl_words); dfree(c->d_vl_nw);
+	c->vl_words_cap = c->vl_tiles_cap = 0;
+	c->vl_valid = false;
+	c->pos_x = c->pos_y = c->pos_z = nullptr;
 	dfree(c->d_key); dfree(c->d_rank); dfree(c->d_perm); dfree(c->d_ckey); dfree(c->d_idk);
 	dfree(c->d_partials);
 	dfree(c->d_exp_leave); dfree(c->d_exp_halo);
@@ -166,6 +172,7 @@ extern "C" int ls1hip_destroy(ls1hip_ctx* c) {
 	dfree(c->d_steplog);
 	if (c->d_ingest) hipFree(c->d_ingest);
 	if (c->h_cnt) hipHostFree(c->h_cnt);
+	if (c->h_flag) hipHostFree((void*)c->h_flag);
 	timer_free(c->t_force); timer_free(c->t_integrate); timer_free(c->t_rebin); timer_free(c->t_halo);
 	hipStreamDestroy(c->stream);
 	if (c->stream2) hipStreamDestroy(c->stream2);
@@ -224,6 +231,9 @@ extern "C" int ls1hip_get_option(const ls1hip_ctx* c, const char* name, long* v)
 	else if (n == "overlap_halo") *v = c->opt_overlap_halo;
 	else if (n == "can_fuse_integration") *v = can_fuse(c) ? 1 : 0;
 	else if (n == "last_force_kernel") *v = c->last_force_kernel;
+	else if (n == "verlet_lists") *v = c->vl_on ? 1 : 0;
+	else if (n == "verlet_builds") *v = (long)c->vl_builds;
+	else if (n == "verlet_steps") *v = (long)c->vl_steps;
 	else return LS1HIP_EINVAL;
 	return LS1HIP_OK;
 }
@@ -337,6 +347,7 @@ extern "C" int ls1hip_set_components(ls1hip_ctx* c, int ncomp, const int* nlj, c
 	t.epsRFInvrc3 = 2. * (eps_rf - 1.) / ((rc * rc * rc) * (2. * eps_rf + 1.));  // VectorizedCellProcessor.cpp:24
 	c->rc = rc;
 	c->rc_lj = rc_lj;
+	c->rc_list = rc + (c->vl_on ? c->vl_skin : 0.);
 	c->one_clj = (ncomp == 1 && tl == 1 && tc == 0 && td == 0 && tq == 0 && !rot && rc == rc_lj);
 	HIPCHK(c, hipSetDevice(c->device));
 	HIPCHK(c, hipMemcpyAsync(c->d_ct, &t, sizeof(t), hipMemcpyHostToDevice, c->stream));
@@ -364,7 +375,7 @@ extern "C" int ls1hip_set_domain(ls1hip_ctx* c, const double global_len[3], cons
 	for (int d = 0; d < 3; ++d)
 		REQUIRE(c, box_max[d] > box_min[d] && box_min[d] >= 0. && box_max[d] <= global_len[d], "bad bounding box");
 	Grid g;
-	if (!grid_init(g, box_min, box_max, c->rc, (int)c->opt_cic))
+	if (!grid_init(g, box_min, box_max, c->rc_list, (int)c->opt_cic))
 		FAIL(c, LS1HIP_EINVAL, "LinkedCells: region too small for the cutoff (or too many cells)");
 	c->g = g;
 	c->my_rank = my_rank;
@@ -442,7 +453,7 @@ static int alloc_mol(ls1hip_ctx* c, size_t n) {
 	for (int d = 0; d < 3; ++d) {
 		const double L = c->g.bmax[d] - c->g.bmin[d];
 		vol *= L;
-		vol_out *= L + 2. * c->rc;
+		vol_out *= L + 2. * c->rc_list;
 	}
 	const double dens = (double)n / vol;
 	size_t cap_real = (size_t)(n * (c->has_remote ? 1.25 : 1.0)) + 1024;
@@ -477,7 +488,9 @@ static int alloc_mol(ls1hip_ctx* c, size_t n) {
 	HaloStage& h = c->hs;
 	(rc = dalloc(c, &h.x, cap_halo)) || (rc = dalloc(c, &h.y, cap_halo)) || (rc = dalloc(c, &h.z, cap_halo)) ||
 		(rc = dalloc(c, &h.id, cap_halo)) || (rc = dalloc(c, &h.cid, cap_halo)) || (rc = dalloc(c, &h.key, cap_halo)) ||
-		(rc = dalloc(c, &h.rank, cap_halo));
+		(rc = dalloc(c, &h.rank, cap_halo)) || (rc = dalloc(c, &h.src, cap_halo)) || (rc = dalloc(c, &h.dir, cap_halo)) ||
+		(rc = dalloc(c, &c->d_halo_src, cap_halo)) || (rc = dalloc(c, &c->d_halo_dir, cap_halo));
+	if (!rc && c->vl_on) (rc = dalloc(c, &c->alt_x, tot)) || (rc = dalloc(c, &c->alt_y, tot)) || (rc = dalloc(c, &c->alt_z, tot));
 	if (!rc && rot)
 		(rc = dalloc(c, &h.q0, cap_halo)) || (rc = dalloc(c, &h.q1, cap_halo)) || (rc = dalloc(c, &h.q2, cap_halo)) ||
 			(rc = dalloc(c, &h.q3, cap_halo));
@@ -499,7 +512,7 @@ static int alloc_mol(ls1hip_ctx* c, size_t n) {
 				if (dir == 13 || c->nbr[dir] < 0 || c->nbr[dir] == c->my_rank) continue;
 				const int s[3] = {sx, sy, sz};
 				double v = 1.;
-				for (int d = 0; d < 3; ++d) v *= (s[d] != 0) ? c->rc : (c->g.bmax[d] - c->g.bmin[d]);
+				for (int d = 0; d < 3; ++d) v *= (s[d] != 0) ? c->rc_list : (c->g.bmax[d] - c->g.bmin[d]);
 				const uint32_t cap = (uint32_t)(dens * v * 1.6) + 2048;
 				offH += cap;
 				offL += cap / 2 + 1024;
@@ -559,7 +572,8 @@ extern "C" int ls1hip_upload_begin(ls1hip_ctx* c, size_t n) {
 	c->n_real = 0;
 	c->n_halo = 0;
 	c->binned = c->halo_valid = c->forces_valid = false;
-	c->pos_in_F = false;
+	c->pos_x = c->pos_y = c->pos_z = nullptr;
+	c->vl_valid = false;
 	c->fused_split = 0;
 	return LS1HIP_OK;
 }
@@ -701,10 +715,10 @@ static RebinArgs rebin_args(ls1hip_ctx* c, uint32_t n_in) {
 	RebinArgs a;
 	a.g = c->g;
 	a.src = c->mol[c->cur];
-	if (c->pos_in_F) {  // a fused force pass left the advanced positions of the owned molecules in the force arrays
-		a.src.x = c->frc.Fx;
-		a.src.y = c->frc.Fy;
-		a.src.z = c->frc.Fz;
+	if (c->pos_x) {  // a fused force pass left the advanced positions of the owned molecules elsewhere (force arrays / alt buffer)
+		a.src.x = c->pos_x;
+		a.src.y = c->pos_y;
+		a.src.z = c->pos_z;
 	}
 	a.dst = c->mol[c->cur ^ 1];
 	a.has_rot = c->h_ct.has_rot;
@@ -731,6 +745,8 @@ static HaloArgs halo_args(ls1hip_ctx* c) {
 	a.perm = c->d_perm; a.count = c->d_count; a.cell_begin = c->d_cell_begin; a.cell_end = c->d_cell_end;
 	a.blocksum = c->d_blocksum;
 	a.idk = c->d_idk;
+	a.hsrc = c->d_halo_src;
+	a.hdir = c->d_halo_dir;
 	a.shell = c->d_shell;
 	a.nshell = c->n_shell;
 	a.cnt = c->d_cnt;
@@ -739,7 +755,7 @@ static HaloArgs halo_args(ls1hip_ctx* c) {
 	memcpy(a.nbr, c->nbr, sizeof(a.nbr));
 	a.my_rank = c->my_rank;
 	memcpy(a.shift, c->shift, sizeof(a.shift));
-	a.rc = c->rc;
+	a.rc = c->rc_list;
 	a.exp_halo = c->d_exp_halo;
 	memcpy(a.exp_off, c->exp_off_halo, sizeof(a.exp_off));
 	a.deterministic = (int)c->opt_det;
@@ -751,7 +767,8 @@ static int do_rebin_finish(ls1hip_ctx* c, uint32_t n_in) {
 	launch_rebin_sort_gather(a, c->stream);
 	HIPCHK(c, hipGetLastError());
 	c->cur ^= 1;
-	c->pos_in_F = false;
+	c->pos_x = c->pos_y = c->pos_z = nullptr;
+	c->vl_valid = false;
 	c->binned = true;
 	c->halo_valid = false;
 	c->forces_valid = false;
@@ -810,8 +827,18 @@ static int before_force_pass(ls1hip_ctx* c, int which) {
 	return LS1HIP_OK;
 }
 
-static int launch_forces(ls1hip_ctx* c, int which, bool fuse = false, double dt = 0.) {
-	ForceParams P;
+// vl: 0 = per-step kernels (search every step), 2 = forces from the stored neighbour lists (kernels_force_verlet.hip).
+// In the list mode the current positions are read from the buffer the previous fused pass wrote (c->pos_*, else
+// mol[cur]) and a fused pass writes the advanced positions to the OTHER of the two position buffers.
+struct ForcePass {
+	int which = 0;
+	bool fuse = false;
+	double dt = 0.;
+	int vl = 0;
+	bool lists_rebuilt = false;  // list mode: the lists were rebuilt in this step (the displacement bound restarts)
+};
+
+static void fill_force_params(ls1hip_ctx* c, ForceParams& P, int which) {
 	memset(&P, 0, sizeof(P));
 	const MolSoA& m = c->mol[c->cur];
 	P.g = c->g;
@@ -830,12 +857,35 @@ static int launch_forces(ls1hip_ctx* c, int which, bool fuse = false, double dt 
 	P.sig2 = c->h_ct.sig2[0];
 	P.shift6 = c->h_ct.shift6[0];
 	P.rc2 = c->h_ct.rc2;
+	P.vl_rc2 = c->rc_list * c->rc_list;
+	P.vl_words = c->d_vl_words;
+	P.vl_nw = c->d_vl_nw;
+}
+
+static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
+	const int which = fp.which;
+	const bool fuse = fp.fuse;
+	ForceParams P;
+	fill_force_params(c, P, which);
+	const MolSoA& m = c->mol[c->cur];
 	if (fuse) {
 		P.fuse = 1;
-		P.dt = dt;
-		P.dt_inv2m = (.5 * dt) / c->h_ct.mass[0];  // as k_kick_then_kick_drift: dt_halve / mass
+		P.dt = fp.dt;
+		P.dt_inv2m = (.5 * fp.dt) / c->h_ct.mass[0];  // as k_kick_then_kick_drift: dt_halve / mass
 		P.mass = c->h_ct.mass[0];
 		P.vx = m.vx; P.vy = m.vy; P.vz = m.vz;
+	}
+	if (fp.vl) {
+		P.vl_mode = 2;
+		if (c->pos_x) {  // current positions (owned + refreshed halo) live in the second buffer
+			P.x = c->pos_x; P.y = c->pos_y; P.z = c->pos_z;
+		}
+		if (fuse) {  // the advanced positions go to the other buffer
+			const bool in_alt = c->pos_x == c->alt_x;
+			P.Fx = in_alt ? m.x : c->alt_x;
+			P.Fy = in_alt ? m.y : c->alt_y;
+			P.Fz = in_alt ? m.z : c->alt_z;
+		}
 	}
 	uint32_t nblocks = 0;
 	// the first pass of a traversal starts the macroscopic sums: the reduction overwrites them (pair counting, a
@@ -845,7 +895,10 @@ static int launch_forces(ls1hip_ctx* c, int which, bool fuse = false, double dt 
 	bool done = false;
 	const double ncell = (double)c->g.box[0] * c->g.box[1] * c->g.box[2];
 	const double mean_per_cell = ncell > 0 ? (double)c->n_real / ncell : 0.;
-	if (c->one_clj && c->opt_force_kernel != LS1HIP_FK_GENERIC && !c->opt_vi && !c->opt_count_pairs) {
+	if (fp.vl) {
+		done = launch_force_verlet(P, c->stream, &nblocks, c->partials_cap, &c->brick_lists);
+		if (!done) FAIL(c, LS1HIP_EINVAL, "neighbour-list force pass could not be launched");
+	} else if (c->one_clj && c->opt_force_kernel != LS1HIP_FK_GENERIC && !c->opt_vi && !c->opt_count_pairs) {
 		done = launch_force_lj(P, c->stream, &nblocks, c->d_partials, c->partials_cap, (int)c->opt_lj_split, mean_per_cell,
 							   &c->brick_lists);
 	} else if (!c->one_clj && c->opt_force_kernel != LS1HIP_FK_GENERIC && !c->opt_count_pairs && which != 3) {
@@ -860,9 +913,29 @@ static int launch_forces(ls1hip_ctx* c, int which, bool fuse = false, double dt 
 		const double nbrs = vol > 0. ? (double)c->n_real / vol * 4.18879 * c->rc * c->rc * c->rc : 0.;
 		launch_force_generic(P, c->one_clj, c->opt_vi != 0, c->h_ct.has_rot != 0, c->stream, &nblocks, nbrs);
 	}
-	launch_force_reduce(c->d_cnt, c->d_partials, nblocks, c->d_stage, c->stream, first_pass && !c->opt_count_pairs, fuse, c->log_row);
+	ReduceMode rm;
+	rm.overwrite = first_pass && !c->opt_count_pairs;
+	rm.kin_in_slot1 = fuse;
+	rm.log = c->log_row;
+	if (fp.vl && fuse) {
+		rm.vmax_in_slot2 = true;
+		rm.last_pass = which != 1;
+		rm.lists_rebuilt = fp.lists_rebuilt;
+		rm.dt = fp.dt;
+		rm.limit = 0.5 * c->vl_skin;
+		rm.seq = ++c->vl_seq;
+		rm.flag = c->d_flag;
+	}
+	launch_force_reduce(c->d_cnt, c->d_partials, nblocks, c->d_stage, c->stream, rm);
 	HIPCHK(c, hipGetLastError());
 	return LS1HIP_OK;
+}
+static int launch_forces(ls1hip_ctx* c, int which, bool fuse = false, double dt = 0.) {
+	ForcePass fp;
+	fp.which = which;
+	fp.fuse = fuse;
+	fp.dt = dt;
+	return launch_forces(c, fp);
 }
 
 static void macro_to_upot_virial(const DevCounters* h, double* upot, double* virial) {
@@ -914,7 +987,8 @@ extern "C" int ls1hip_forces_kick_drift(ls1hip_ctx* c, int which, double dt, dou
 	} else {
 		// velocities are at t + dt/2 of the NEXT step and the advanced positions wait in the force arrays for ls1hip_rebin
 		c->fused_split = 0;
-		c->pos_in_F = true;
+		c->pos_x = c->frc.Fx; c->pos_y = c->frc.Fy; c->pos_z = c->frc.Fz;
+		c->vl_valid = false;
 		c->binned = false;
 		c->halo_valid = false;
 		c->forces_valid = false;
@@ -929,14 +1003,14 @@ extern "C" int ls1hip_forces_kick_drift(ls1hip_ctx* c, int which, double dt, dou
 
 // positions parked in the force arrays by a fused pass -> back into the molecule arrays (readers other than ls1hip_rebin)
 static int materialise_positions(ls1hip_ctx* c) {
-	if (!c->pos_in_F) return LS1HIP_OK;
+	if (!c->pos_x) return LS1HIP_OK;
 	const MolSoA& m = c->mol[c->cur];
 	const uint32_t n = (uint32_t)c->n_real;
-	launch_pack_copy(m.x, c->frc.Fx, n, c->stream);
-	launch_pack_copy(m.y, c->frc.Fy, n, c->stream);
-	launch_pack_copy(m.z, c->frc.Fz, n, c->stream);
+	launch_pack_copy(m.x, c->pos_x, n, c->stream);
+	launch_pack_copy(m.y, c->pos_y, n, c->stream);
+	launch_pack_copy(m.z, c->pos_z, n, c->stream);
 	HIPCHK(c, hipGetLastError());
-	c->pos_in_F = false;
+	c->pos_x = c->pos_y = c->pos_z = nullptr;
 	return LS1HIP_OK;
 }
 
@@ -956,7 +1030,13 @@ static IntegArgs integ_args(ls1hip_ctx* c, double dt) {
 extern "C" int ls1hip_kick_drift(ls1hip_ctx* c, double dt) {
 	if (!c) return LS1HIP_EINVAL;
 	REQUIRE(c, c->cap_real, "no molecules uploaded");
-	REQUIRE(c, !c->pos_in_F && !c->fused_split, "positions were already advanced by ls1hip_forces_kick_drift (call ls1hip_rebin)");
+	REQUIRE(c, !c->fused_split, "a fused inner pass is waiting for its boundary pass");
+	REQUIRE(c, !c->pos_x || c->forces_valid, "positions were already advanced by ls1hip_forces_kick_drift (call ls1hip_rebin)");
+	if (c->pos_x) {  // list-reuse run that ended with an unfused step: the positions live in the second buffer
+		int rcm = materialise_positions(c);
+		if (rcm) return rcm;
+	}
+	c->vl_valid = false;
 	HIPCHK(c, hipSetDevice(c->device));
 	TimedScope ts(c, c->t_integrate);
 	launch_kick_drift(integ_args(c, dt), c->stream);
@@ -972,6 +1052,11 @@ extern "C" int ls1hip_kick_then_kick_drift(ls1hip_ctx* c, double dt) {
 	REQUIRE(c, c->forces_valid, "forces are not valid (call ls1hip_forces)");
 	REQUIRE(c, !c->thermostat_on, "with the device thermostat the two half kicks are separate passes (kick, scale, kick_drift)");
 	HIPCHK(c, hipSetDevice(c->device));
+	if (c->pos_x) {
+		int rcm = materialise_positions(c);
+		if (rcm) return rcm;
+	}
+	c->vl_valid = false;
 	TimedScope ts(c, c->t_integrate);
 	launch_kick_then_kick_drift(integ_args(c, dt), c->stream);
 	HIPCHK(c, hipGetLastError());
@@ -1102,6 +1187,99 @@ extern "C" int ls1hip_long_range_homogeneous(ls1hip_ctx* c, const uint64_t* nmol
 	return LS1HIP_OK;
 }
 
+// ---- neighbour-list reuse ---------------------------------------------------------------------------------------------
+extern "C" int ls1hip_set_verlet(ls1hip_ctx* c, int enabled, double skin) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, !enabled || skin > 0., "the skin must be positive");
+	REQUIRE(c, !c->have_domain, "ls1hip_set_verlet must be called before ls1hip_set_domain (the cell grid depends on rc + skin)");
+	c->vl_on = enabled != 0;
+	c->vl_skin = enabled ? skin : 0.;
+	c->rc_list = c->rc + c->vl_skin;
+	c->vl_valid = false;
+	return LS1HIP_OK;
+}
+
+// the list-reuse loop serves what the fused per-step loop serves, on a single rank with one cell per cutoff
+static bool can_verlet(const ls1hip_ctx* c) { return c->vl_on && can_fuse(c) && c->g.hw == 1 && !c->has_remote; }
+
+static int ensure_verlet_buffers(ls1hip_ctx* c) {
+	long nbricks;
+	size_t wpb, tpb;
+	verlet_geometry(c->g, &nbricks, &wpb, &tpb);
+	const size_t words = (size_t)nbricks * wpb, tiles = (size_t)nbricks * tpb;
+	if (words > c->vl_words_cap || tiles > c->vl_tiles_cap) {
+		dfree(c->d_vl_words);
+		dfree(c->d_vl_nw);
+		c->vl_words_cap = c->vl_tiles_cap = 0;
+		int rc;
+		if ((rc = dalloc(c, &c->d_vl_words, words)) || (rc = dalloc(c, &c->d_vl_nw, tiles))) return rc;
+		c->vl_words_cap = words;
+		c->vl_tiles_cap = tiles;
+	}
+	if (!c->h_flag) {
+		void* h = nullptr;
+		HIPCHK(c, hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent));
+		c->h_flag = (volatile uint32_t*)h;
+		*c->h_flag = 0;
+		void* d = nullptr;
+		HIPCHK(c, hipHostGetDevicePointer(&d, h, 0));
+		c->d_flag = (uint32_t*)d;
+	}
+	return LS1HIP_OK;
+}
+
+// lists of all bricks from the freshly binned molecules + halo copies in mol[cur]
+static int verlet_build(ls1hip_ctx* c) {
+	int rc = ensure_verlet_buffers(c);
+	if (rc) return rc;
+	TimedScope ts(c, c->t_rebin);  // list construction belongs to the re-binning work of a rebuild step
+	ForceParams P;
+	fill_force_params(c, P, 0);
+	P.vl_mode = 1;
+	uint32_t nb = 0;
+	if (!launch_force_verlet(P, c->stream, &nb, c->partials_cap, &c->brick_lists))
+		FAIL(c, LS1HIP_EINVAL, "neighbour lists could not be built for this grid");
+	HIPCHK(c, hipGetLastError());
+	c->vl_builds++;
+	return LS1HIP_OK;
+}
+
+// halo positions of the current position buffer from their source molecules (no re-binning, no image generation)
+static int verlet_refresh_halo(ls1hip_ctx* c) {
+	TimedScope ts(c, c->t_halo);
+	HaloArgs a = halo_args(c);
+	const MolSoA& m = c->mol[c->cur];
+	double *x = c->pos_x ? c->pos_x : m.x, *y = c->pos_x ? c->pos_y : m.y, *z = c->pos_x ? c->pos_z : m.z;
+	launch_halo_refresh(a, x, y, z, x, y, z, c->stream);
+	HIPCHK(c, hipGetLastError());
+	return LS1HIP_OK;
+}
+
+// result of the step's last reduction: does the displacement bound exceed skin / 2?  (host-visible word, polled: the
+// kernels of the next step cannot be chosen before it is known; a stream synchronisation costs ~10 us more)
+static int verlet_poll_rebuild(ls1hip_ctx* c, bool* need) {
+	const uint32_t want = c->vl_seq;
+	for (long spin = 0;; ++spin) {
+		const uint32_t f = *c->h_flag;
+		if ((f >> 1) == want) {
+			*need = (f & 1u) != 0;
+			return LS1HIP_OK;
+		}
+		if ((spin & 0xffff) == 0xffff) {  // a failed launch would never publish: ask the runtime now and then
+			hipError_t e = hipStreamQuery(c->stream);
+			if (e == hipSuccess) {
+				const uint32_t g = *c->h_flag;
+				if ((g >> 1) == want) {
+					*need = (g & 1u) != 0;
+					return LS1HIP_OK;
+				}
+				FAIL(c, LS1HIP_EHIP, "the rebuild flag of step sequence %u was never published", want);
+			}
+			if (e != hipErrorNotReady) FAIL(c, LS1HIP_EHIP, "stream error while waiting for the rebuild flag: %s", hipGetErrorString(e));
+		}
+	}
+}
+
 extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double* out6) {
 	if (!c) return LS1HIP_EINVAL;
 	REQUIRE(c, !c->has_remote, "ls1hip_run drives single-rank domains only (use the piecewise calls with a transport)");
@@ -1110,6 +1288,7 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 	// Between two steps of an NVE run on the LJ fast path the force pass does the integration itself (fused mode, the
 	// reference's reduced-memory scheme); the last step is unfused so that F and the kinetic sums are available.
 	const bool fuse = c->opt_fuse && can_fuse(c);
+	const bool verlet = fuse && can_verlet(c);
 	bool advanced = false;  // the previous force pass already did kick + kick + drift
 	// step log: one row {U_pot, virial, sum m v^2, sum I w^2, N, rotDOF} per step, written by the reductions on the device
 	if (!c->d_steplog) {
@@ -1143,21 +1322,61 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 			// post-force kick of step s-1 fused with the pre-force kick+drift of step s (same F, one pass)
 			if ((rc = ls1hip_kick_then_kick_drift(c, dt))) return rc;
 		}
-		if ((rc = ls1hip_rebin(c))) return rc;
+		const bool was_advanced = advanced;
 		advanced = fuse && s + 1 < nsteps;
-		if (c->opt_overlap_halo == 2) {
+		if (verlet) {
+			// neighbour-list loop: the lists, the binning and the halo slots live until the displacement bound of the
+			// molecules (accumulated on the device) exceeds skin / 2; then re-bin, regenerate the halo, rebuild the lists
+			bool rebuild = true;
+			if (was_advanced && c->vl_valid && (rc = verlet_poll_rebuild(c, &rebuild))) return rc;
+			if (rebuild) {
+				if ((rc = ls1hip_rebin(c)) || (rc = ls1hip_halo(c)) || (rc = verlet_build(c))) return rc;
+			} else {
+				if ((rc = verlet_refresh_halo(c))) return rc;
+			}
+			{
+				TimedScope ts(c, c->t_force);
+				ForcePass fp;
+				fp.which = 0;
+				fp.fuse = advanced;
+				fp.dt = dt;
+				fp.vl = 2;
+				fp.lists_rebuilt = rebuild;
+				if ((rc = launch_forces(c, fp))) return rc;
+			}
+			c->vl_steps++;
+			if (advanced) {
+				// velocities are at t + dt/2 of the next step; the advanced positions wait in the other position buffer
+				const bool in_alt = c->pos_x == c->alt_x;
+				const MolSoA& m = c->mol[c->cur];
+				c->pos_x = in_alt ? nullptr : c->alt_x;
+				c->pos_y = in_alt ? nullptr : c->alt_y;
+				c->pos_z = in_alt ? nullptr : c->alt_z;
+				(void)m;
+				c->vl_valid = true;
+				c->halo_valid = false;
+				c->forces_valid = false;
+			} else {
+				c->forces_valid = true;
+				c->halo_valid = true;
+				c->vl_valid = false;  // an unfused pass does not advance the displacement bound
+			}
+		} else if (c->opt_overlap_halo == 2) {
+			if ((rc = ls1hip_rebin(c))) return rc;
 			// halo first, then the inner and the boundary cells as two passes of the same stream
 			if ((rc = ls1hip_halo(c))) return rc;
 			rc = advanced ? ls1hip_forces_kick_drift(c, 1, dt, nullptr, nullptr) : ls1hip_forces(c, 1, nullptr, nullptr);
 			if (rc) return rc;
 			rc = advanced ? ls1hip_forces_kick_drift(c, 2, dt, nullptr, nullptr) : ls1hip_forces(c, 2, nullptr, nullptr);
 		} else if (c->opt_overlap_halo) {
+			if ((rc = ls1hip_rebin(c))) return rc;
 			// inner-cell pass first (it needs the owned molecules only); the periodic images are generated and sorted
 			// on the second stream while it runs; the boundary pass waits for them on the device
 			rc = advanced ? ls1hip_forces_kick_drift(c, 1, dt, nullptr, nullptr) : ls1hip_forces(c, 1, nullptr, nullptr);
 			if (rc || (rc = ls1hip_halo(c))) return rc;
 			rc = advanced ? ls1hip_forces_kick_drift(c, 2, dt, nullptr, nullptr) : ls1hip_forces(c, 2, nullptr, nullptr);
 		} else {
+			if ((rc = ls1hip_rebin(c))) return rc;
 			if ((rc = ls1hip_halo(c))) return rc;
 			rc = advanced ? ls1hip_forces_kick_drift(c, 0, dt, nullptr, nullptr) : ls1hip_forces(c, 0, nullptr, nullptr);
 		}
@@ -1170,6 +1389,16 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 				launch_scale(integ_args(c, 0.), 1., 1., true, c->stream);
 			}
 		}
+	}
+	if (verlet && c->pos_x) {
+		// leave the state where every other entry point expects it: positions (owned + halo) in mol[cur]
+		const MolSoA& m = c->mol[c->cur];
+		const uint32_t n = (uint32_t)(c->n_real + c->cap_halo);
+		launch_pack_copy(m.x, c->pos_x, n, c->stream);
+		launch_pack_copy(m.y, c->pos_y, n, c->stream);
+		launch_pack_copy(m.z, c->pos_z, n, c->stream);
+		HIPCHK(c, hipGetLastError());
+		c->pos_x = c->pos_y = c->pos_z = nullptr;
 	}
 	c->steplog_steps = nsteps;
 	int rc = sync_counters(c);
@@ -1230,6 +1459,25 @@ extern "C" int ls1hip_download_state(ls1hip_ctx* c, size_t cap, uint64_t* id, in
 	if (id) HIPCHK(c, hipMemcpy(id, m.id, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
 	if (cid) HIPCHK(c, hipMemcpy(cid, m.cid, n * sizeof(int32_t), hipMemcpyDeviceToHost));
 	if (r && (rc = d2h3(c, n, m.x, m.y, m.z, r, 3, 0))) return rc;
+	if (r && c->vl_on) {
+		// between two rebuilds of the neighbour lists a molecule may sit up to skin / 2 outside the box: report it wrapped
+		// (same rule and rounding clamps as the re-binning pass, DomainDecompBase.cpp:206-219)
+		for (int k = 0; k < 3; ++k) {
+			const int st = k == 0 ? 1 : (k == 1 ? 3 : 9);
+			if (c->nbr[13 + st] != c->my_rank || c->nbr[13 - st] != c->my_rank) continue;
+			const double lo = c->g.bmin[k], hi = c->g.bmax[k], len = c->global_len[k];
+			for (size_t i = 0; i < n; ++i) {
+				double& x = r[3 * i + k];
+				if (x < lo) {
+					x += len;
+					if (x >= hi) x = std::nextafter(hi, lo);
+				} else if (x >= hi) {
+					x -= len;
+					if (x <= lo) x = lo;
+				}
+			}
+		}
+	}
 	if (v && (rc = d2h3(c, n, m.vx, m.vy, m.vz, v, 3, 0))) return rc;
 	if (q) {
 		if (c->h_ct.has_rot) {
@@ -1552,7 +1800,7 @@ extern "C" int ls1hip_soa_forces(ls1hip_ctx* c, const int cell_dims[3], const ui
 	launch_clear_macro(c->d_cnt, c->stream);
 	if (n) {
 		launch_force_generic(P, c->one_clj, true, rot, c->stream, &nblocks);
-		launch_force_reduce(c->d_cnt, part, nblocks, c->d_stage, c->stream);
+		launch_force_reduce(c->d_cnt, part, nblocks, c->d_stage, c->stream, ReduceMode());
 	}
 	rc = sync_counters(c);
 	if (!rc) {

@@ -45,6 +45,7 @@ __device__ __forceinline__ void block_scan_lds(uint32_t* v, int n, uint32_t* wsu
 struct BrickSel {
 	int x0, y0, z0;  // brick origin in grid cell coordinates
 	int ex, ey, ez;  // extent in cells (edge bricks are partial)
+	int id;          // linear brick index (bz * nby + by) * nbx + bx — independent of the launch order / pass
 	bool live;
 };
 template <int HW, int BX, int BY, int BZ>
@@ -65,6 +66,7 @@ __device__ __forceinline__ BrickSel brick_select(const ForceParams& P, int nbx, 
 		by = (brick / nbx) % nby;
 		bz = brick / (nbx * nby);
 	}
+	b.id = (bz * nby + by) * nbx + bx;
 	b.x0 = HW + bx * BX;
 	b.y0 = HW + by * BY;
 	b.z0 = HW + bz * BZ;

@@ -35,6 +35,8 @@ struct HaloStage {  // unsorted halo copies (local images + imported records)
 	uint64_t* id;
 	int32_t* cid;
 	uint32_t *key, *rank;
+	uint32_t* src;  // owned index of the molecule a LOCAL image copies (0xffffffff for imported records)
+	uint8_t* dir;   // direction (0..26) of the image: its shift is shift[dir]
 };
 
 // device-side counters / flags, one small struct in device memory (no host sync needed inside the step)
@@ -50,6 +52,8 @@ struct DevCounters {
 	uint32_t err_ingest;   // uploaded molecules outside the bounding box of this rank / with a wrong component id
 	uint32_t err_ingest_first;  // index (in upload order) of one offending molecule
 	unsigned long long dist_checks, pairs_in_range;
+	double vmax2;          // list-reuse mode: max |v|^2 of the drift velocities of the current step
+	double vl_bound;       // upper bound of the displacement of any molecule since the neighbour lists were built
 	double macro[4];       // u6, uX, rf, virial of the current traversal
 	double kin[2];         // sum m v^2, sum I w^2
 	double beta[2];        // thermostat factors derived from kin (beta_trans, beta_rot)
@@ -80,6 +84,11 @@ struct ForceParams {
 	double *vx, *vy, *vz;
 	// 1CLJ fast-path scalars
 	double eps24, sig2, shift6, rc2;
+	// neighbour-list reuse (kernels_force_verlet.hip): 0 off, 1 build the lists (no forces), 2 forces from the lists
+	int vl_mode;
+	double vl_rc2;       // (rc + skin)^2: list cutoff
+	uint64_t* vl_words;  // [brick][tile][word][64 lanes]: 4 u16 LDS byte offsets per word
+	uint8_t* vl_nw;      // [brick][tile]: words per lane in use (wave maximum), 0xff = overflow -> direct evaluation
 };
 
 // inner / boundary brick lists of the LJ brick kernels for the current grid and brick shape (kernels_force_lj.hip)
@@ -116,7 +125,9 @@ struct ls1hip_ctx {
 	// modes 0 / 1 / 2); 1 inner-cell pass first with the halo phase on the second stream meanwhile; 2 halo, inner, boundary
 	long opt_overlap_halo = 0;
 	long opt_fuse = 1;       // ls1hip_run: fuse force + integration between steps when possible
-	bool pos_in_F = false;   // positions of the owned molecules live in frc.F* (after a fused force pass)
+	// where the CURRENT positions live when not in mol[cur].x/y/z: the force arrays after a fused per-step pass, the second
+	// position buffer (alt_*) in the list-reuse mode; nullptr = mol[cur]
+	double *pos_x = nullptr, *pos_y = nullptr, *pos_z = nullptr;
 	int fused_split = 0;     // a fused which=1 pass is waiting for its which=2 pass
 	// model
 	bool have_comp = false, have_domain = false;
@@ -161,6 +172,21 @@ struct ls1hip_ctx {
 	int timing_on = 0;  // 0 off, 1 all phases, 2 force passes only
 	ls1::Timer t_force, t_integrate, t_rebin, t_halo;
 	std::vector<void*> allocs;
+	// neighbour-list reuse (ls1hip_set_verlet; kernels_force_verlet.hip)
+	bool vl_on = false;
+	double vl_skin = 0.;
+	double rc_list = 0.;  // rc + skin: cutoff of the cell grid, the halo shell and the lists
+	uint64_t* d_vl_words = nullptr;
+	uint8_t* d_vl_nw = nullptr;
+	size_t vl_words_cap = 0, vl_tiles_cap = 0;
+	double *alt_x = nullptr, *alt_y = nullptr, *alt_z = nullptr;  // second position buffer (owned + halo segment)
+	bool vl_valid = false;       // the lists match the current binning and the displacement bound is tracked on the device
+	uint32_t *d_halo_src = nullptr;
+	uint8_t* d_halo_dir = nullptr;
+	volatile uint32_t* h_flag = nullptr;  // host-visible {seq << 1 | rebuild needed}, written by the step's last reduction
+	uint32_t* d_flag = nullptr;
+	uint32_t vl_seq = 0;
+	unsigned long vl_builds = 0, vl_steps = 0;
 	// per-step globals of ls1hip_run (ls1hip_run_log): rows of 6 doubles, written by the reduction kernels
 	double* d_steplog = nullptr;
 	double *log_row = nullptr, *log_row_kin = nullptr;  // rows the next force / kinetic reduction refreshes (null outside ls1hip_run)
@@ -198,6 +224,8 @@ struct HaloArgs {
 	Grid g;
 	MolSoA mol;  // current set; halo segment is written at [n_real, ...)
 	HaloStage hs;
+	uint32_t* hsrc;  // per sorted halo copy: owned index of its source molecule / direction of its shift (list-reuse
+	uint8_t* hdir;   // mode refreshes the halo positions from these instead of regenerating the images)
 	bool has_rot;
 	uint32_t *perm, *count, *cell_begin, *cell_end, *blocksum;
 	uint64_t* idk;  // ids of the staged halo copies in slot order (canonical in-cell order by counting, as in k_gather)
@@ -216,6 +244,9 @@ struct HaloArgs {
 void launch_halo_generate(const HaloArgs& a, hipStream_t s);
 void launch_halo_import(const HaloArgs& a, const double* dev_records, uint32_t n, hipStream_t s);
 void launch_halo_finalize(const HaloArgs& a, hipStream_t s);
+// positions of the halo copies recomputed from their source molecules: dst[n_real + k] = src[hsrc[k]] + shift[hdir[k]]
+void launch_halo_refresh(const HaloArgs& a, const double* sx, const double* sy, const double* sz, double* dx, double* dy,
+						 double* dz, hipStream_t s);
 void launch_leave_import(const RebinArgs& a, const double* dev_records, uint32_t n, uint32_t at, hipStream_t s);
 void launch_pack_copy(double* dst, const double* src, uint32_t ndoubles, hipStream_t s);
 // up to 27 (source offset -> destination offset) runs of doubles copied by one launch; dst_off is ascending
@@ -255,13 +286,29 @@ void launch_force_generic(const ForceParams& p, bool one_clj, bool with_vi, bool
 // LDS-tiled 1CLJ kernel (kernels_force_lj.hip); returns false if it cannot handle the configuration
 bool launch_force_lj(const ForceParams& p, hipStream_t s, uint32_t* nblocks, double* partials, size_t partials_cap,
 					 int split, double mean_per_cell, BrickLists* bl);
+// neighbour-list (Verlet) variant of the 1CLJ fast path (kernels_force_verlet.hip): p.vl_mode 1 builds the lists of ALL
+// bricks, 2 evaluates the forces of the bricks of pass p.which from them
+bool launch_force_verlet(const ForceParams& p, hipStream_t s, uint32_t* nblocks, size_t partials_cap, BrickLists* bl);
+void verlet_geometry(const Grid& g, long* nbricks, size_t* words_per_brick, size_t* tiles_per_brick);
 // brick-tiled multi-site kernel (kernels_force_ms.hip); returns false if it cannot handle the configuration
 bool launch_force_ms(const ForceParams& p, bool with_vi, bool has_rot, hipStream_t s, uint32_t* nblocks, size_t partials_cap,
 					 double mean_per_cell, BrickLists* bl);
 // kin_in_slot1: the partials' slot 1 carries sum m v^2 of a fused force + integration pass (goes to cnt->kin[0], not to
 // the macroscopic sums); log (may be null): the step-log row {U_pot, virial, sum m v^2, sum I w^2, N, rotDOF} to refresh
+struct ReduceMode {
+	bool overwrite = false;     // first pass of a traversal: the sums start here
+	bool kin_in_slot1 = false;  // slot 1 = sum m v^2 of a fused pass
+	double* log = nullptr;      // step-log row to refresh
+	// list-reuse mode: slot 2 = max |v_drift|^2 (combined by max).  On the LAST pass of a step the displacement bound is
+	// advanced by dt * sqrt(vmax2) (after being reset when the lists were rebuilt in this step) and the rebuild flag
+	// {seq, bound > limit} is published to the host-visible word `flag`.
+	bool vmax_in_slot2 = false, last_pass = false, lists_rebuilt = false;
+	double dt = 0., limit = 0.;
+	uint32_t seq = 0;
+	volatile uint32_t* flag = nullptr;
+};
 void launch_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, double* stage, hipStream_t s,
-						 bool overwrite = false, bool kin_in_slot1 = false, double* log = nullptr);
+						 const ReduceMode& m);
 void launch_clear_macro(DevCounters* cnt, hipStream_t s);
 
 struct IntegArgs {

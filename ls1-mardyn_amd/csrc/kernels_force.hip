@@ -21,6 +21,10 @@ namespace ls1 {
 
 constexpr int FTPB = 128;
 
+__device__ __forceinline__ double wave_max(double v) {
+	for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o));
+	return v;
+}
 __device__ __forceinline__ double wave_sum(double v) {
 	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
 	return v;
@@ -278,24 +282,37 @@ void launch_clear_macro(DevCounters* cnt, hipStream_t s) { hipLaunchKernelGGL(k_
 // deterministic reduction of the per-workgroup partials in two fixed-shape stages (RED_BLOCKS x 256 threads, then one
 // block), ADDED to cnt->macro; the summation order depends only on the number of partials, never on timing.
 constexpr int RED_BLOCKS = 128;
-__global__ void __launch_bounds__(256) k_force_reduce1(const double* partials, uint32_t nblocks, double* stage) {
+__global__ void __launch_bounds__(256) k_force_reduce1(const double* partials, uint32_t nblocks, double* stage, int max2) {
 	double v[4] = {0., 0., 0., 0.};
 	for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < nblocks; b += RED_BLOCKS * 256)
-		for (int k = 0; k < 4; ++k) v[k] += partials[(size_t)b * 4 + k];
+		for (int k = 0; k < 4; ++k) {
+			const double x = partials[(size_t)b * 4 + k];
+			v[k] = (k == 2 && max2) ? fmax(v[k], x) : v[k] + x;
+		}
 	__shared__ double red[4][4];
-	for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
+	for (int k = 0; k < 4; ++k) v[k] = (k == 2 && max2) ? wave_max(v[k]) : wave_sum(v[k]);
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	if (lane == 0)
 		for (int k = 0; k < 4; ++k) red[w][k] = v[k];
 	__syncthreads();
-	if (threadIdx.x < 4) stage[blockIdx.x * 4 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+	if (threadIdx.x < 4) {
+		const int k = threadIdx.x;
+		stage[blockIdx.x * 4 + k] = (k == 2 && max2) ? fmax(fmax(red[0][k], red[1][k]), fmax(red[2][k], red[3][k]))
+													  : red[0][k] + red[1][k] + red[2][k] + red[3][k];
+	}
 }
-__global__ void __launch_bounds__(RED_BLOCKS) k_force_reduce2(DevCounters* cnt, const double* stage, int overwrite, int kin_in_slot1,
-															   double* log) {
+struct Reduce2Args {
+	int overwrite, kin_in_slot1, vmax_in_slot2, last_pass, lists_rebuilt;
+	double dt, limit;
+	uint32_t seq;
+	volatile uint32_t* flag;
+	double* log;
+};
+__global__ void __launch_bounds__(RED_BLOCKS) k_force_reduce2(DevCounters* cnt, const double* stage, Reduce2Args m) {
 	double v[4];
 	for (int k = 0; k < 4; ++k) v[k] = stage[threadIdx.x * 4 + k];
 	__shared__ double red[RED_BLOCKS / 64][4];
-	for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
+	for (int k = 0; k < 4; ++k) v[k] = (k == 2 && m.vmax_in_slot2) ? wave_max(v[k]) : wave_sum(v[k]);
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	if (lane == 0)
 		for (int k = 0; k < 4; ++k) red[w][k] = v[k];
@@ -304,39 +321,57 @@ __global__ void __launch_bounds__(RED_BLOCKS) k_force_reduce2(DevCounters* cnt, 
 		double s[4];
 		for (int k = 0; k < 4; ++k) {
 			s[k] = 0.;
-			for (int i = 0; i < RED_BLOCKS / 64; ++i) s[k] += red[i][k];
+			for (int i = 0; i < RED_BLOCKS / 64; ++i) s[k] = (k == 2 && m.vmax_in_slot2) ? fmax(s[k], red[i][k]) : s[k] + red[i][k];
 		}
-		if (kin_in_slot1) {
+		if (m.kin_in_slot1) {
 			// fused force + integration pass: slot 1 is sum m v^2 after the post-force kick (Leapfrog.cpp:115-131)
-			cnt->kin[0] = overwrite ? s[1] : cnt->kin[0] + s[1];
+			cnt->kin[0] = m.overwrite ? s[1] : cnt->kin[0] + s[1];
 			cnt->kin[1] = 0.;
 			cnt->kin_n = cnt->n_real;
 			cnt->kin_rotdof = 0;
 			s[1] = 0.;
 		}
-		for (int k = 0; k < 4; ++k) cnt->macro[k] = overwrite ? s[k] : cnt->macro[k] + s[k];  // first pass of a traversal starts the sums
-		if (log) {
+		if (m.vmax_in_slot2) {
+			cnt->vmax2 = m.overwrite ? s[2] : fmax(cnt->vmax2, s[2]);
+			s[2] = 0.;
+			if (m.last_pass) {
+				// every molecule moves by at most dt * vmax in this step: the sum over the steps since the lists were built
+				// bounds the displacement of any molecule (triangle inequality); the lists hold all pairs within rc + skin at
+				// build time, so they stay complete while 2 * bound <= skin
+				const double b = (m.lists_rebuilt ? 0. : cnt->vl_bound) + m.dt * sqrt(cnt->vmax2);
+				cnt->vl_bound = b;
+				if (m.flag) {
+					__threadfence_system();
+					*m.flag = (m.seq << 1) | (b > m.limit ? 1u : 0u);
+					__threadfence_system();
+				}
+			}
+		}
+		for (int k = 0; k < 4; ++k) cnt->macro[k] = m.overwrite ? s[k] : cnt->macro[k] + s[k];  // first pass of a traversal starts the sums
+		if (m.log) {
 			// VectorizedCellProcessor::endTraversal (VectorizedCellProcessor.cpp:155-156) + the kinetic sums of this step
-			log[0] = cnt->macro[0] / 6.0 + cnt->macro[1] + cnt->macro[2];
-			log[1] = cnt->macro[3] + 3.0 * cnt->macro[2];
-			if (kin_in_slot1) {
-				log[2] = cnt->kin[0];
-				log[3] = 0.;
-				log[4] = (double)cnt->kin_n;
-				log[5] = 0.;
+			m.log[0] = cnt->macro[0] / 6.0 + cnt->macro[1] + cnt->macro[2];
+			m.log[1] = cnt->macro[3] + 3.0 * cnt->macro[2];
+			if (m.kin_in_slot1) {
+				m.log[2] = cnt->kin[0];
+				m.log[3] = 0.;
+				m.log[4] = (double)cnt->kin_n;
+				m.log[5] = 0.;
 			}
 		}
 	}
 }
 
-void launch_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, double* stage, hipStream_t s, bool overwrite,
-						 bool kin_in_slot1, double* log) {
+void launch_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, double* stage, hipStream_t s, const ReduceMode& m) {
 	if (nblocks == 0) {
-		if (overwrite) launch_clear_macro(cnt, s);
+		if (m.overwrite) launch_clear_macro(cnt, s);
 		return;
 	}
-	hipLaunchKernelGGL(k_force_reduce1, dim3(RED_BLOCKS), dim3(256), 0, s, partials, nblocks, stage);
-	hipLaunchKernelGGL(k_force_reduce2, dim3(1), dim3(RED_BLOCKS), 0, s, cnt, stage, overwrite ? 1 : 0, kin_in_slot1 ? 1 : 0, log);
+	Reduce2Args a;
+	a.overwrite = m.overwrite; a.kin_in_slot1 = m.kin_in_slot1; a.vmax_in_slot2 = m.vmax_in_slot2; a.last_pass = m.last_pass;
+	a.lists_rebuilt = m.lists_rebuilt; a.dt = m.dt; a.limit = m.limit; a.seq = m.seq; a.flag = m.flag; a.log = m.log;
+	hipLaunchKernelGGL(k_force_reduce1, dim3(RED_BLOCKS), dim3(256), 0, s, partials, nblocks, stage, m.vmax_in_slot2 ? 1 : 0);
+	hipLaunchKernelGGL(k_force_reduce2, dim3(1), dim3(RED_BLOCKS), 0, s, cnt, stage, a);
 }
 
 }  // namespace ls1

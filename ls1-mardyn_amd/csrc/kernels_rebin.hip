@@ -375,7 +375,9 @@ void launch_pack_copy(double* dst, const double* src, uint32_t ndoubles, hipStre
 
 // ---- halo copies --------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void halo_stage_write(const HaloArgs& a, uint32_t slot, const double r[3], uint64_t id,
-												  int32_t cid, double q0, double q1, double q2, double q3) {
+												  int32_t cid, double q0, double q1, double q2, double q3, uint32_t src, int dir) {
+	a.hs.src[slot] = src;
+	a.hs.dir[slot] = (uint8_t)dir;
 	a.hs.x[slot] = r[0];
 	a.hs.y[slot] = r[1];
 	a.hs.z[slot] = r[2];
@@ -457,7 +459,7 @@ __device__ __forceinline__ void halo_emit(const HaloArgs& a, uint32_t p, const d
 			atomicAdd(&a.cnt->err_overflow, 1u);
 			return;
 		}
-		halo_stage_write(a, slot, rn, id, cid, q0, q1, q2, q3);
+		halo_stage_write(a, slot, rn, id, cid, q0, q1, q2, q3, p, dir);
 	} else {
 		const uint32_t cap = a.exp_off[dir + 1] - a.exp_off[dir];
 		if (slot >= cap) {
@@ -564,7 +566,7 @@ __global__ void __launch_bounds__(HI_TPB) k_halo_import(HaloArgs a, const double
 	}
 	const double rr[3] = {r[2], r[3], r[4]};
 	halo_stage_write(a, slot, rr, (uint64_t)__double_as_longlong(r[0]), (int32_t)__double_as_longlong(r[1]), r[5], r[6],
-					 r[7], r[8]);
+					 r[7], r[8], 0xffffffffu, 13);
 }
 
 __global__ void __launch_bounds__(TPB) k_halo_gather(HaloArgs a) {
@@ -581,6 +583,8 @@ __global__ void __launch_bounds__(TPB) k_halo_gather(HaloArgs a) {
 		const uint64_t myid = a.idk[k];
 		p = n_real + cb + rank_by_id(a.idk, cb, ce, k, myid);
 	}
+	a.hsrc[p - n_real] = a.hs.src[i];
+	a.hdir[p - n_real] = a.hs.dir[i];
 	a.mol.x[p] = a.hs.x[i];
 	a.mol.y[p] = a.hs.y[i];
 	a.mol.z[p] = a.hs.z[i];
@@ -628,6 +632,26 @@ __global__ void __launch_bounds__(TPB) k_halo_scatter(HaloArgs a) {
 	const uint32_t slot = a.cell_begin[k] + a.hs.rank[i] - a.cnt->n_real;
 	a.perm[slot] = i;
 	a.idk[slot] = a.hs.id[i];
+}
+
+// List-reuse mode: between two rebuilds the halo copies keep their slots; only their positions follow the source
+// molecules (image = source + shift of its direction; the rounding guards of the generation only matter for binning).
+__global__ void __launch_bounds__(TPB) k_halo_refresh(HaloArgs a, const double* sx, const double* sy, const double* sz, double* dx,
+													  double* dy, double* dz) {
+	const uint32_t k = blockIdx.x * TPB + threadIdx.x;
+	if (k >= a.cnt->n_halo) return;
+	const uint32_t src = a.hsrc[k];
+	if (src == 0xffffffffu) return;  // imported copy: refreshed by its owner's message
+	const int dir = a.hdir[k];
+	const uint32_t p = a.cnt->n_real + k;
+	dx[p] = sx[src] + a.shift[dir][0];
+	dy[p] = sy[src] + a.shift[dir][1];
+	dz[p] = sz[src] + a.shift[dir][2];
+}
+void launch_halo_refresh(const HaloArgs& a, const double* sx, const double* sy, const double* sz, double* dx, double* dy,
+						 double* dz, hipStream_t s) {
+	if (a.cap_halo == 0) return;
+	hipLaunchKernelGGL(k_halo_refresh, dim3((a.cap_halo + TPB - 1) / TPB), dim3(TPB), 0, s, a, sx, sy, sz, dx, dy, dz);
 }
 
 void launch_halo_finalize(const HaloArgs& a, hipStream_t s) {

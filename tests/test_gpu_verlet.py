@@ -1,0 +1,188 @@
+"""GPU parity tests of the neighbour-list (Verlet) loop of ls1hip_run (ls1hip_set_verlet, kernels_force_verlet.hip):
+against the REAL reference's golden trajectory, against the pinned oracle step by step, and against the per-step
+kernels over several list lifetimes; plus the rebuild trigger, the list-overflow / unstaged fallbacks and the shifted
+potential.  Tolerances: trajectories 1e-9 (as for the per-step kernels), forces of one evaluation 1e-12 of max|F|."""
+import numpy as np
+import pytest
+
+from conftest import load_pkg
+from golden_io import input_path, manifest, read_golden, rel_componentwise, rel_max, sorted_phase_space
+from oracle.oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+inp = load_pkg("inp")
+capi = load_pkg("capi")
+engine_mod = load_pkg("engine")
+synth = load_pkg("synth")
+MAN = manifest()
+
+
+def _lj(rc=2.5, shift=0):
+    return inp.ComponentSet([inp.make_component(lj=[(0, 0, 0, 1, 1, 1, rc, shift)])], np.zeros((0, 2)), 1e10)
+
+
+def _engine(comps, rc, L, ids, r, v, skin=None, **opts):
+    e = engine_mod.DeviceEngine(0)
+    e.set_components(comps, rc)
+    for k, val in opts.items():
+        e.set_option(k, val)
+    e.set_verlet(skin)
+    e.set_domain(L)
+    e.upload(ids, np.zeros(len(ids), np.int32), r, v)
+    e.rebin(); e.halo(); e.forces(0)
+    return e
+
+
+def _state(e):
+    st = e.download_state()
+    o = np.argsort(st["ids"], kind="stable")
+    return st["ids"][o], st["r"][o], st["v"][o], e.download_forces()["F"][o]
+
+
+@pytest.mark.parametrize("skin", [0.3, 0.12])
+def test_verlet_run_matches_reference_trajectory(skin):
+    """10 Leapfrog steps of the REAL reference (bcc1clj_3456_steps10) with the list-reuse loop."""
+    name = "bcc1clj_3456_steps10"
+    case = MAN[name]
+    g = read_golden(name)
+    ps = inp.read_inp(input_path(case["input"]))
+    st = sorted_phase_space(ps)
+    e = _engine(ps.components, case["rc"], ps.length, st["ids"], st["r"], st["v"], skin=skin)
+    assert e.get_option("verlet_lists") == 1
+    out = e.run(case["dt"], case["steps"])
+    assert e.get_option("verlet_steps") == case["steps"] and 1 <= e.get_option("verlet_builds") < case["steps"]
+    ids, r, v, F = _state(e)
+    rec = g["recs"]
+    L = ps.length
+    assert r.min() >= 0 and np.all(r < L)  # reported wrapped although the lists outlive a periodic crossing
+    dr = r - rec["r"]
+    dr -= L * np.round(dr / L)
+    assert np.max(np.abs(dr)) < 1e-9 * np.max(L)
+    assert rel_max(v, rec["v"]) < 1e-9
+    assert rel_max(F, rec["F"]) < 1e-8 and rel_componentwise(F, rec["F"]) < 1e-7
+    assert abs(out["upot"] - g["upot"]) / abs(g["upot"]) < 1e-9
+    assert abs(out["virial"] - g["virial"]) / abs(g["virial"]) < 1e-8
+    assert abs(out["summv2"] - g["summv2"]) / abs(g["summv2"]) < 1e-9
+    # every step's globals against the pinned oracle
+    log = e.run_log()
+    orc = Oracle(ps.components.flat(), case["rc"])
+    ro, vo, q, D, cid = st["r"].copy(), st["v"].copy(), st["q"].copy(), st["D"].copy(), st["cid"]
+    o = orc.forces(ro, q, cid, ps.length, True)
+    Fo, Mo = o["F"].copy(), o["M"].copy()
+    for s in range(case["steps"]):
+        o = orc.step(case["dt"], cid, ro, vo, q, D, Fo, Mo, ps.length, True)
+        assert abs(log[s, 0] - o["upot"]) <= 1e-9 * abs(o["upot"]), s
+        assert abs(log[s, 1] - o["virial"]) <= 1e-8 * abs(o["virial"]), s
+        assert abs(log[s, 2] - o["summv2"]) <= 1e-9 * o["summv2"], s
+    e.close()
+
+
+@pytest.mark.parametrize("n,temp,dt,steps", [(24, 0.95, 0.002, 80), (20, 12.0, 0.002, 40)])
+def test_verlet_loop_equals_per_step_kernels_over_many_rebuilds(n, temp, dt, steps):
+    """Several list lifetimes (and, hot, a rebuild every few steps): same trajectory as the per-step MFMA kernel loop;
+    the rebuild count follows the displacement bound (skin / 2 over dt * vmax), not a fixed interval."""
+    L, ids, r, v = synth.bcc_box(n, temp=temp)
+    res = {}
+    for mode, skin in (("step", None), ("list", 0.3)):
+        e = _engine(_lj(), 2.5, [L] * 3, ids, r, v, skin=skin)
+        out = e.run(dt, steps)
+        res[mode] = _state(e) + (out, e.run_log())
+        if skin:
+            builds = e.get_option("verlet_builds")
+            vmax = np.sqrt((v * v).sum(1).max())
+            lo = int(steps * dt * vmax * 0.5 / (0.5 * skin))  # ballistic estimate, halved: speeds relax
+            assert max(1, lo) <= builds <= steps // 2 + 1, (builds, lo)
+        e.close()
+    a, b = res["step"], res["list"]
+    assert np.array_equal(a[0], b[0])
+    dr = a[1] - b[1]
+    dr -= L * np.round(dr / L)
+    assert np.max(np.abs(dr)) < 1e-10 * L
+    assert rel_max(b[2], a[2]) < 1e-10
+    assert rel_max(b[3], a[3]) < 1e-9
+    for k in ("upot", "virial", "summv2"):
+        assert abs(a[4][k] - b[4][k]) <= 1e-10 * abs(a[4][k]), k
+    assert np.allclose(a[5][:, :3], b[5][:, :3], rtol=1e-10, atol=0)
+
+
+def test_verlet_single_evaluation_forces_and_shifted_potential():
+    """One list build + evaluation vs the generic kernel on the same state, unshifted and shifted LJ (the in-range pair
+    count that carries the shift is only tallied when the shift is non-zero)."""
+    L, ids, r, v = synth.bcc_box(16)
+    for shift in (0, 1):
+        comps = _lj(2.5, shift)
+        ref = _engine(comps, 2.5, [L] * 3, ids, r, v, force_kernel=capi.FK_GENERIC)
+        o0 = ref.run(1e-9, 1)
+        F0 = _state(ref)[3]
+        ref.close()
+        e = _engine(comps, 2.5, [L] * 3, ids, r, v, skin=0.25)
+        out = e.run(1e-9, 1)  # one (unfused) list build + evaluation
+        assert e.get_option("verlet_builds") == 1
+        F = _state(e)[3]
+        assert rel_max(F, F0) < 1e-12
+        assert abs(out["upot"] - o0["upot"]) <= 1e-11 * abs(o0["upot"]) and abs(out["virial"] - o0["virial"]) <= 1e-11 * abs(o0["virial"])
+        e.close()
+
+
+def test_verlet_dense_cluster_fallbacks():
+    """Neighbourhoods longer than the list capacity (96 entries) and brick shells larger than the staging area fall back to
+    direct evaluation with the same arithmetic: dense gas blob in a big box, against the generic kernel."""
+    rng = np.random.default_rng(5)
+    L = 40.0
+    # jittered lattices (minimum distance 0.35): a blob of 6 molecules per unit volume (~390 neighbours inside rc = 2.5)
+    # inside a dilute gas
+    g = np.arange(14.0, 26.0, 0.55)
+    blob = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3) + rng.uniform(-0.1, 0.1, (len(g) ** 3, 3))
+    h = np.arange(1.0, L, 2.0)
+    rest = np.stack(np.meshgrid(h, h, h, indexing="ij"), -1).reshape(-1, 3) + rng.uniform(-0.3, 0.3, (len(h) ** 3, 3))
+    rest = rest[~np.all((rest > 13.0) & (rest < 27.0), axis=1)]
+    r = np.concatenate([blob, rest])
+    n = len(r)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    v = rng.normal(0, 0.3, (n, 3))
+    # weakly interacting (eps 1e-3, sigma 0.3): the blob is dense in NEIGHBOURS, not in energy, so a few steps stay tame
+    soft = inp.ComponentSet([inp.make_component(lj=[(0, 0, 0, 1, 1e-3, 0.3, 2.5, 0)])], np.zeros((0, 2)), 1e10)
+    _lj = lambda: soft  # noqa: E731
+    ref = _engine(_lj(), 2.5, [L] * 3, ids, r, v, force_kernel=capi.FK_GENERIC)
+    o0 = ref.run(1e-9, 1)
+    F0 = _state(ref)[3]
+    ref.close()
+    e = _engine(_lj(), 2.5, [L] * 3, ids, r, v, skin=0.3)
+    out = e.run(1e-9, 1)
+    F = _state(e)[3]
+    assert rel_max(F, F0) < 1e-11
+    assert abs(out["upot"] - o0["upot"]) <= 1e-10 * abs(o0["upot"]) and abs(out["virial"] - o0["virial"]) <= 1e-10 * abs(o0["virial"])
+    # and a few fused steps through the fallbacks stay on the per-step kernels' trajectory
+    e2 = _engine(_lj(), 2.5, [L] * 3, ids, r, v)
+    a = e2.run(0.0005, 6)
+    e3 = _engine(_lj(), 2.5, [L] * 3, ids, r, v, skin=0.3)
+    b = e3.run(0.0005, 6)
+    assert rel_max(_state(e3)[2], _state(e2)[2]) < 1e-9
+    assert abs(a["upot"] - b["upot"]) <= 1e-9 * abs(a["upot"])
+    for x in (e, e2, e3):
+        x.close()
+
+
+def test_verlet_state_rules():
+    """The list loop leaves the context where the piecewise entry points expect it, and they invalidate the lists."""
+    L, ids, r, v = synth.bcc_box(12)
+    e = _engine(_lj(), 2.5, [L] * 3, ids, r, v, skin=0.3)
+    with pytest.raises(capi.Ls1HipError):
+        e.set_verlet(0.2)  # after set_domain
+    e.run(0.002, 5)
+    b0 = e.get_option("verlet_builds")
+    # piecewise step after a list run: plain entry points on the same context
+    e.kick_drift(0.002); e.rebin(); e.halo()
+    u, w = e.forces(0)
+    e.kick(0.001)
+    e.run(0.002, 5)  # starts with an unfused drift: rebuilds first
+    assert e.get_option("verlet_builds") > b0
+    # reference: per-step kernels for the same 11 steps
+    e2 = _engine(_lj(), 2.5, [L] * 3, ids, r, v)
+    e2.run(0.002, 5)
+    e2.kick_drift(0.002); e2.rebin(); e2.halo(); e2.forces(0); e2.kick(0.001)
+    e2.run(0.002, 5)
+    a, b = _state(e), _state(e2)
+    assert rel_max(a[2], b[2]) < 1e-10 and rel_max(a[3], b[3]) < 1e-9
+    e.close(); e2.close()

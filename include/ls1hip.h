@@ -232,7 +232,9 @@ int ls1hip_long_range_homogeneous(ls1hip_ctx* ctx, const uint64_t* n_per_compone
  * FP64).  Between rebuilds there is no search, no re-binning and no halo regeneration.  Must be called after
  * ls1hip_set_components and before ls1hip_set_domain.  Positions reported by the download calls are wrapped into the box.
  * Precedent in the reference: the Verlet-list containers behind particleContainer/AutoPasContainer.cpp:281-346
- * (verletSkinRadius / verletRebuildFrequency).  Read-only options "verlet_lists", "verlet_builds", "verlet_steps". */
+ * (verletSkinRadius / verletRebuildFrequency).  enabled = 1: used when the mean population of a brick's region fits the
+ * LDS staging area of the list kernels (otherwise ls1hip_run keeps the per-step kernels); 2: always (bricks that do not fit
+ * are evaluated from global memory: correct, slow — for tests).  Read-only options "verlet_lists", "verlet_builds", "verlet_steps". */
 int ls1hip_set_verlet(ls1hip_ctx* ctx, int enabled, double skin);
 
 /* nsteps full time steps entirely on the device (single rank, all directions local), no host round trip

@@ -1193,6 +1193,7 @@ extern "C" int ls1hip_set_verlet(ls1hip_ctx* c, int enabled, double skin) {
 	REQUIRE(c, !enabled || skin > 0., "the skin must be positive");
 	REQUIRE(c, !c->have_domain, "ls1hip_set_verlet must be called before ls1hip_set_domain (the cell grid depends on rc + skin)");
 	c->vl_on = enabled != 0;
+	c->vl_force = enabled == 2;
 	c->vl_skin = enabled ? skin : 0.;
 	c->rc_list = c->rc + c->vl_skin;
 	c->vl_valid = false;
@@ -1200,7 +1201,14 @@ extern "C" int ls1hip_set_verlet(ls1hip_ctx* c, int enabled, double skin) {
 }
 
 // the list-reuse loop serves what the fused per-step loop serves, on a single rank with one cell per cutoff
-static bool can_verlet(const ls1hip_ctx* c) { return c->vl_on && can_fuse(c) && c->g.hw == 1 && !c->has_remote; }
+static bool can_verlet(const ls1hip_ctx* c) {
+	if (!(c->vl_on && can_fuse(c) && c->g.hw == 1 && !c->has_remote)) return false;
+	// a brick region that does not fit the LDS staging area is evaluated from global memory (correct but slow): if the
+	// MEAN region already comes close to the capacity (large skin, dense system), the per-step kernels are the better loop
+	const double ncell = (double)c->g.box[0] * c->g.box[1] * c->g.box[2];
+	const double mean_region = ncell > 0. ? (double)c->n_real / ncell * verlet_region_cells() : 0.;
+	return c->vl_force || mean_region * 1.06 <= (double)verlet_region_capacity();
+}
 
 static int ensure_verlet_buffers(ls1hip_ctx* c) {
 	long nbricks;

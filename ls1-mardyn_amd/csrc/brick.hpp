@@ -48,13 +48,15 @@ struct BrickSel {
 	int id;          // linear brick index (bz * nby + by) * nbx + bx — independent of the launch order / pass
 	bool live;
 };
+// vb / vgrid: (virtual) workgroup index and grid size — blockIdx.x / gridDim.x for one brick per workgroup; persistent
+// kernels walk vb = blockIdx.x + k * gridDim.x over a virtual grid (gridDim.x a multiple of 8 keeps vb % 8 = the XCD)
 template <int HW, int BX, int BY, int BZ>
-__device__ __forceinline__ BrickSel brick_select(const ForceParams& P, int nbx, int nby, int nbz) {
+__device__ __forceinline__ BrickSel brick_select_v(const ForceParams& P, int nbx, int nby, int nbz, int vb, int vgrid) {
 	const int nb = P.inner_box ? P.inner_n[0] * P.inner_n[1] * P.inner_n[2] : (P.brick_list ? (int)P.n_list : nbx * nby * nbz);
-	const int chunk = gridDim.x / 8;
-	const int slot = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
+	const int chunk = vgrid / 8;
+	const int slot = (vb % 8) * chunk + vb / 8;
 	BrickSel b;
-	b.live = slot < nb;
+	b.live = vb < vgrid && slot < nb;
 	int bx = 0, by = 0, bz = 0;
 	if (b.live && P.inner_box) {
 		bx = P.inner_lo[0] + slot % P.inner_n[0];
@@ -79,6 +81,10 @@ __device__ __forceinline__ BrickSel brick_select(const ForceParams& P, int nbx, 
 		b.live = (P.which == 1) ? inner : !inner;
 	}
 	return b;
+}
+template <int HW, int BX, int BY, int BZ>
+__device__ __forceinline__ BrickSel brick_select(const ForceParams& P, int nbx, int nby, int nbz) {
+	return brick_select_v<HW, BX, BY, BZ>(P, nbx, nby, nbz, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Cell table of the brick's region (brick + cutoff shell) in region-linear order: gbeg[c] = global index of the first

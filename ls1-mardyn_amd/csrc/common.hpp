@@ -173,7 +173,7 @@ struct ls1hip_ctx {
 	ls1::Timer t_force, t_integrate, t_rebin, t_halo;
 	std::vector<void*> allocs;
 	// neighbour-list reuse (ls1hip_set_verlet; kernels_force_verlet.hip)
-	bool vl_on = false;
+	bool vl_on = false, vl_force = false;
 	double vl_skin = 0.;
 	double rc_list = 0.;  // rc + skin: cutoff of the cell grid, the halo shell and the lists
 	uint64_t* d_vl_words = nullptr;
@@ -290,6 +290,8 @@ bool launch_force_lj(const ForceParams& p, hipStream_t s, uint32_t* nblocks, dou
 // bricks, 2 evaluates the forces of the bricks of pass p.which from them
 bool launch_force_verlet(const ForceParams& p, hipStream_t s, uint32_t* nblocks, size_t partials_cap, BrickLists* bl);
 void verlet_geometry(const Grid& g, long* nbricks, size_t* words_per_brick, size_t* tiles_per_brick);
+int verlet_region_capacity();  // molecules of a brick's region the list kernels can stage in LDS
+int verlet_region_cells();
 // brick-tiled multi-site kernel (kernels_force_ms.hip); returns false if it cannot handle the configuration
 bool launch_force_ms(const ForceParams& p, bool with_vi, bool has_rot, hipStream_t s, uint32_t* nblocks, size_t partials_cap,
 					 double mean_per_cell, BrickLists* bl);

@@ -220,10 +220,11 @@ class DeviceEngine:
     def set_thermostat(self, enabled: bool, target_temperature: float = 0.0):
         self._chk(self.lib.ls1hip_set_thermostat(self.ctx, int(bool(enabled)), float(target_temperature)))
 
-    def set_verlet(self, skin: float | None):
-        """Neighbour-list reuse in run() (skin > 0) or off (None / 0); call between set_components and set_domain."""
+    def set_verlet(self, skin: float | None, force: bool = False):
+        """Neighbour-list reuse in run() (skin > 0) or off (None / 0); call between set_components and set_domain.
+        force: also when the brick regions exceed the LDS staging area (slow global-memory path; tests)."""
         on = bool(skin) and skin > 0
-        self._chk(self.lib.ls1hip_set_verlet(self.ctx, int(on), float(skin) if on else 0.0))
+        self._chk(self.lib.ls1hip_set_verlet(self.ctx, (2 if force else 1) if on else 0, float(skin) if on else 0.0))
 
     def long_range_homogeneous(self, n_per_component, global_rho):
         n = np.ascontiguousarray(n_per_component, dtype=np.uint64)

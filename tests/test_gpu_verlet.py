@@ -27,7 +27,7 @@ def _engine(comps, rc, L, ids, r, v, skin=None, **opts):
     e.set_components(comps, rc)
     for k, val in opts.items():
         e.set_option(k, val)
-    e.set_verlet(skin)
+    e.set_verlet(skin, force=True)
     e.set_domain(L)
     e.upload(ids, np.zeros(len(ids), np.int32), r, v)
     e.rebin(); e.halo(); e.forces(0)

@@ -37,6 +37,14 @@ if kd and "FETCH_SIZE" in kern[kd[0]]:
                               "FETCH_SIZE_bytes_raw": k["FETCH_SIZE"] * 1024, "WRITE_SIZE_bytes_raw": k["WRITE_SIZE"] * 1024,
                               "fetch_correction": 72.0 * n / (k["FETCH_SIZE"] * 1024)}
 fk = [k for k in kern if "k_force_" in k and "reduce" not in k]
+# the dominant force kernel = the one with the largest total time in the kernel trace (list build / per-step kernels of
+# the first step also match the name pattern)
+tot = {}
+for f in glob.glob(os.path.join(out, "kernel_stats.csv")):
+    for r in csv.DictReader(open(f)):
+        tot[r["Name"].split("(")[0].replace("void ", "")] = float(r["TotalDurationNs"])
+fk.sort(key=lambda name: -tot.get(name, 0.0))
+summary["force_kernels_by_time_ms"] = {name: tot.get(name, 0.0) / 1e6 for name in fk}
 if fk:
     k = kern[fk[0]]
     alg = bench["roofline"]["algorithmic_bytes_per_launch"]

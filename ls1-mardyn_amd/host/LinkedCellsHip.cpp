@@ -1,0 +1,352 @@
+// LinkedCellsHip.cpp — seam B (see LinkedCellsHip.h): the ParticleContainer and Integrator the unmodified
+// Simulation.cpp constructs, forwarding the hot path to libls1hip (include/ls1hip.h) and every host-side service to a
+// real reference LinkedCells object kept as the lazily synced mirror.
+//
+// One time step as the unmodified driver runs it (Simulation.cpp:979-1167) and where each call lands:
+//   _integrator->eventNewTimestep          LeapfrogHip: [velocity scaling with the driver's betas] + ls1hip_kick_drift
+//   _moleculeContainer->update             ls1hip_rebin (wrap + counting sort on the device)
+//   _domainDecomposition->balanceAndExchange   the reference's host loops find an empty region iterator (no-op); the
+//                                          periodic wrap / halo copies they would make are done by ls1hip_rebin / ls1hip_halo
+//   _moleculeContainer->updateMoleculeCaches   ls1hip_halo
+//   _moleculeContainer->traverseCells      ls1hip_forces -> Domain::setLocalUpot / setLocalVirial (as AutoPasContainer does,
+//                                          particleContainer/AutoPasContainer.cpp:348-395)
+//   updateForces (calcFM loop)             iterates the emptied mirror: no-op (site reduction is fused in the force kernel)
+//   _moleculeContainer->deleteOuterParticles   no-op (the halo segment is rebuilt every step)
+//   _integrator->eventForcesCalculated     LeapfrogHip: ls1hip_kick -> Domain::setLocalSummv2 / SumIw2 / NrotDOF
+//   _domain->calculateGlobalValues         unchanged reference code on those sums (beta factors)
+//   _velocityScalingThermostat.apply       iterates the emptied mirror: no-op; the betas are applied on the device at the
+//                                          head of the next eventNewTimestep (same position in the sequence of kicks)
+#include "LinkedCellsHip.h"
+
+#include <cstdlib>
+
+#include "Domain.h"
+#include "Simulation.h"
+#include "ensemble/EnsembleBase.h"
+#include "molecules/Molecule.h"
+#include "parallel/DomainDecompBase.h"
+#include "particleContainer/adapter/VectorizedCellProcessor.h"
+#include "utils/Logger.h"
+#include "utils/xmlfileUnits.h"
+
+#include "ls1hip_components.hpp"
+
+using Log::global_log;
+
+void LinkedCellsHip::die(const char* what, int rc) const {
+	global_log->error() << "LinkedCellsHip: " << what << " failed (" << rc << "): " << ls1hip_last_error(_ctx) << std::endl;
+	Simulation::exit(680 - rc);
+}
+
+LinkedCellsHip::LinkedCellsHip() : ParticleContainer(), _mirror() {
+	global_log->info() << "LinkedCellsHip: device-resident container, MI355X/HIP back end (" << ls1hip_version() << ")" << std::endl;
+}
+
+LinkedCellsHip::LinkedCellsHip(double bBoxMin[3], double bBoxMax[3], double cutoffRadius)
+	: ParticleContainer(bBoxMin, bBoxMax), _mirror(bBoxMin, bBoxMax, cutoffRadius) {}
+
+LinkedCellsHip::~LinkedCellsHip() {
+	if (_ctx) ls1hip_destroy(_ctx);
+}
+
+void LinkedCellsHip::readXML(XMLfileUnits& xmlconfig) { _mirror.readXML(xmlconfig); }
+
+bool LinkedCellsHip::rebuild(double bBoxMin[3], double bBoxMax[3]) {
+	for (int d = 0; d < 3; ++d) {
+		_boundingBoxMin[d] = bBoxMin[d];
+		_boundingBoxMax[d] = bBoxMax[d];
+	}
+	_hostDirty = true;  // the device grid is derived from the box at the next upload
+	return _mirror.rebuild(bBoxMin, bBoxMax);
+}
+
+// ---- host-side population: everything goes to the mirror ---------------------------------------------------------------
+bool LinkedCellsHip::addParticle(Molecule& particle, bool inBoxCheckedAlready, bool checkWhetherDuplicate,
+								 const bool& rebuildCaches) {
+	if (_inExchange) return false;  // (unreachable: the exchange window sees empty region iterators)
+	if (!_mirrorFresh) syncMirrorFromDevice();
+	_hostDirty = true;
+	return _mirror.addParticle(particle, inBoxCheckedAlready, checkWhetherDuplicate, rebuildCaches);
+}
+
+bool LinkedCellsHip::addHaloParticle(Molecule& particle, bool inBoxCheckedAlready, bool checkWhetherDuplicate,
+									 const bool& rebuildCaches) {
+	// halo copies are generated on the device (ls1hip_halo); host-side copies would only matter to host traversals
+	(void)particle; (void)inBoxCheckedAlready; (void)checkWhetherDuplicate; (void)rebuildCaches;
+	return false;
+}
+
+void LinkedCellsHip::addParticles(std::vector<Molecule>& particles, bool checkWhetherDuplicate) {
+	if (!_mirrorFresh) syncMirrorFromDevice();
+	_hostDirty = true;
+	_mirror.addParticles(particles, checkWhetherDuplicate);
+}
+
+unsigned long LinkedCellsHip::initCubicGrid(std::array<unsigned long, 3> numMoleculesPerDimension,
+											std::array<double, 3> simBoxLength, size_t seed_offset) {
+	_hostDirty = true;
+	_mirrorFresh = true;
+	return _mirror.initCubicGrid(numMoleculesPerDimension, simBoxLength, seed_offset);
+}
+
+void LinkedCellsHip::clear() {
+	_mirror.clear();
+	_mirrorFresh = true;
+	_hostDirty = true;
+	_uploaded = false;
+}
+
+void LinkedCellsHip::deleteMolecule(ParticleIterator& moleculeIter, const bool& rebuildCaches) {
+	// the iterator can only point into a fresh mirror (a stale one is empty)
+	_mirror.deleteMolecule(moleculeIter, rebuildCaches);
+	_hostDirty = true;
+}
+
+double LinkedCellsHip::getEnergy(ParticlePairsHandler* particlePairsHandler, Molecule* m1, CellProcessor& cellProcessor) {
+	if (!_mirrorFresh) syncMirrorFromDevice();
+	return _mirror.getEnergy(particlePairsHandler, m1, cellProcessor);  // grand-canonical insertions: host path of the reference
+}
+
+std::variant<ParticleIterator, SingleCellIterator<ParticleCell>> LinkedCellsHip::getMoleculeAtPosition(const double pos[3]) {
+	if (!_mirrorFresh) syncMirrorFromDevice();
+	return _mirror.getMoleculeAtPosition(pos);
+}
+
+ParticleIterator LinkedCellsHip::iterator(ParticleIterator::Type t) { return _mirror.iterator(t); }
+
+RegionParticleIterator LinkedCellsHip::regionIterator(const double startCorner[3], const double endCorner[3],
+													   ParticleIterator::Type t) {
+	if (_inExchange) return RegionParticleIterator();  // DomainDecompBase::exchangeMolecules: done on the device
+	return _mirror.regionIterator(startCorner, endCorner, t);
+}
+
+unsigned long LinkedCellsHip::getNumberOfParticles() {
+	if (_uploaded && !_hostDirty) {
+		size_t n = 0, h = 0;
+		ls1hip_count(_ctx, &n, &h);
+		return (unsigned long)n;
+	}
+	return _mirror.getNumberOfParticles();
+}
+
+std::vector<unsigned long> LinkedCellsHip::getParticleCellStatistics() { return _mirror.getParticleCellStatistics(); }
+std::string LinkedCellsHip::getConfigurationAsString() { return _mirror.getConfigurationAsString() + " (device-resident, libls1hip)"; }
+size_t LinkedCellsHip::getTotalSize() { return _mirror.getTotalSize(); }
+void LinkedCellsHip::printSubInfo(int offset) { _mirror.printSubInfo(offset); }
+
+// ---- device side ------------------------------------------------------------------------------------------------------------
+void LinkedCellsHip::uploadFromMirror() {
+	Simulation* sim = global_simulation;
+	Domain* domain = sim->getDomain();
+	if (sim->domainDecomposition().getNumProcs() != 1) {
+		global_log->error() << "LinkedCellsHip: this adapter serves the sequential / single-rank driver; multi-rank runs go "
+							   "through the export / import entry points of ls1hip.h (INTEGRATION.md)" << std::endl;
+		Simulation::exit(681);
+	}
+	int rc;
+	if (!_ctx) {
+		int device = 0;
+		if (const char* e = getenv("LS1HIP_DEVICE")) device = atoi(e);
+		if ((rc = ls1hip_create(device, &_ctx))) die("ls1hip_create", rc);
+	}
+	if ((rc = ls1hip_set_components_from(_ctx, *(sim->getEnsemble()->getComponents()), *domain, sim->getcutoffRadius(),
+										 sim->getLJCutoff())))
+		die("ls1hip_set_components", rc);
+	if ((rc = ls1hip_set_option(_ctx, "cells_in_cutoff", _mirror.getHaloWidthNumCells()))) die("ls1hip_set_option", rc);
+	double glen[3], bmin[3], bmax[3];
+	int nbr[27];
+	for (int d = 0; d < 3; ++d) {
+		glen[d] = domain->getGlobalLength(d);
+		bmin[d] = _mirror.getBoundingBoxMin(d);
+		bmax[d] = _mirror.getBoundingBoxMax(d);
+	}
+	for (int k = 0; k < 27; ++k) nbr[k] = 0;  // DomainDecompBase: every side is periodic onto this rank
+	if ((rc = ls1hip_set_domain(_ctx, glen, bmin, bmax, 0, nbr))) die("ls1hip_set_domain", rc);
+	std::vector<uint64_t> id;
+	std::vector<int32_t> cid;
+	std::vector<double> r, v, q, D;
+	const unsigned long n0 = _mirror.getNumberOfParticles();
+	id.reserve(n0); cid.reserve(n0); r.reserve(3 * n0); v.reserve(3 * n0); q.reserve(4 * n0); D.reserve(3 * n0);
+	for (auto m = _mirror.iterator(ParticleIterator::ONLY_INNER_AND_BOUNDARY); m.isValid(); ++m) {
+		id.push_back(m->getID());
+		cid.push_back((int32_t)m->componentid());
+		for (int d = 0; d < 3; ++d) {
+			r.push_back(m->r(d));
+			v.push_back(m->v(d));
+			D.push_back(m->D(d));
+		}
+		q.push_back(m->q().qw()); q.push_back(m->q().qx()); q.push_back(m->q().qy()); q.push_back(m->q().qz());
+	}
+	if ((rc = ls1hip_upload(_ctx, id.size(), id.data(), cid.data(), r.data(), v.data(), q.data(), D.data()))) die("ls1hip_upload", rc);
+	_uploaded = true;
+	_hostDirty = false;
+}
+
+void LinkedCellsHip::update() {
+	if (_hostDirty || !_uploaded) {
+		if (!_mirrorFresh) {
+			global_log->error() << "LinkedCellsHip: molecules were changed on the host while the mirror was stale" << std::endl;
+			Simulation::exit(682);
+		}
+		_mirror.update();
+		uploadFromMirror();
+	}
+	int rc = ls1hip_rebin(_ctx);
+	if (rc) die("ls1hip_rebin", rc);
+	_inExchange = true;
+}
+
+void LinkedCellsHip::updateMoleculeCaches() {
+	_inExchange = false;
+	int rc = ls1hip_halo(_ctx);
+	if (rc) die("ls1hip_halo", rc);
+	if (_mirrorFresh) _mirror.updateMoleculeCaches();  // keeps calcFM on mirror molecules (prepare_start) well defined
+}
+void LinkedCellsHip::updateInnerMoleculeCaches() {}
+void LinkedCellsHip::updateBoundaryAndHaloMoleculeCaches() { updateMoleculeCaches(); }
+
+void LinkedCellsHip::deleteOuterParticles() {
+	if (_mirrorFresh) _mirror.deleteOuterParticles();  // device: the halo segment is rebuilt by every ls1hip_halo
+}
+
+void LinkedCellsHip::deviceForces(int which) {
+	double upot = 0., virial = 0.;
+	const bool want = which != 1;
+	int rc = ls1hip_forces(_ctx, which, want ? &upot : nullptr, want ? &virial : nullptr);
+	if (rc) die("ls1hip_forces", rc);
+	if (want) {
+		// what VectorizedCellProcessor::endTraversal publishes (VectorizedCellProcessor.cpp:155-156)
+		Domain* domain = global_simulation->getDomain();
+		domain->setLocalUpot(upot);
+		domain->setLocalVirial(virial);
+	}
+}
+
+static void require_vectorized(CellProcessor& cp) {
+	if (dynamic_cast<VectorizedCellProcessor*>(&cp) == nullptr) {
+		global_log->error() << "LinkedCellsHip: only the force traversal (VectorizedCellProcessor) runs on the device container; "
+							   "other cell processors need the host container" << std::endl;
+		Simulation::exit(683);
+	}
+}
+
+void LinkedCellsHip::traverseCells(CellProcessor& cellProcessor) {
+	require_vectorized(cellProcessor);
+	deviceForces(0);
+}
+void LinkedCellsHip::traverseNonInnermostCells(CellProcessor& cellProcessor) {
+	require_vectorized(cellProcessor);
+	deviceForces(2);
+}
+void LinkedCellsHip::traversePartialInnermostCells(CellProcessor& cellProcessor, unsigned int stage, int stageCount) {
+	require_vectorized(cellProcessor);
+	(void)stageCount;
+	if (stage == 0) deviceForces(1);  // the whole inner pass is one launch: it runs entirely at stage 0
+}
+
+void LinkedCellsHip::deviceAdvanced() {
+	if (_mirrorFresh) {
+		_mirror.clear();  // stale from here on: its iterators stay valid and yield nothing
+		_mirrorFresh = false;
+	}
+}
+
+void LinkedCellsHip::syncMirrorFromDevice() {
+	if (!_uploaded) return;
+	size_t n = 0, h = 0;
+	ls1hip_count(_ctx, &n, &h);
+	std::vector<uint64_t> id(n);
+	std::vector<int32_t> cid(n);
+	std::vector<double> r(3 * n), v(3 * n), q(4 * n), D(3 * n), F(3 * n), M(3 * n);
+	int rc = ls1hip_download_state(_ctx, n, id.data(), cid.data(), r.data(), v.data(), q.data(), D.data());
+	if (rc) die("ls1hip_download_state", rc);
+	const bool haveF = ls1hip_download_forces(_ctx, n, F.data(), M.data(), nullptr) == LS1HIP_OK;
+	std::vector<Component>& comps = *(global_simulation->getEnsemble()->getComponents());
+	_mirror.clear();
+	std::vector<Molecule> mols;
+	mols.reserve(n);
+	for (size_t i = 0; i < n; ++i) {
+		Molecule m(id[i], &comps[cid[i]], r[3 * i], r[3 * i + 1], r[3 * i + 2], v[3 * i], v[3 * i + 1], v[3 * i + 2], q[4 * i],
+				   q[4 * i + 1], q[4 * i + 2], q[4 * i + 3], D[3 * i], D[3 * i + 1], D[3 * i + 2]);
+		if (haveF) {
+			m.setF(&F[3 * i]);
+			m.setM(&M[3 * i]);
+		}
+		mols.push_back(m);
+	}
+	_mirror.addParticles(mols);
+	_mirror.updateMoleculeCaches();
+	_mirrorFresh = true;
+	_hostDirty = false;
+}
+
+// ---- integrator -------------------------------------------------------------------------------------------------------------
+static LinkedCellsHip* device_container(ParticleContainer* c) {
+	LinkedCellsHip* p = dynamic_cast<LinkedCellsHip*>(c);
+	if (!p || !p->deviceReady()) {
+		global_log->error() << "LeapfrogHip needs the device container (LinkedCellsHip) with its molecules uploaded" << std::endl;
+		Simulation::exit(684);
+	}
+	return p;
+}
+
+void LeapfrogHip::readXML(XMLfileUnits& xmlconfig) {
+	_timestepLength = 0;
+	xmlconfig.getNodeValueReduced("timestep", _timestepLength);
+	global_log->info() << "Timestep: " << _timestepLength << " (LeapfrogHip: integration on the device)" << std::endl;
+}
+
+void LeapfrogHip::init() { _state = STATE_POST_FORCE_CALCULATION; }
+
+void LeapfrogHip::eventNewTimestep(ParticleContainer* moleculeContainer, Domain* domain) {
+	if (_state != STATE_POST_FORCE_CALCULATION) return;
+	LinkedCellsHip* cont = device_container(moleculeContainer);
+	ls1hip_ctx* ctx = cont->context();
+	int rc;
+	if (_haveBeta && !domain->NVE()) {
+		// VelocityScalingThermostat::apply of the step just finished (Simulation.cpp:1108-1131), global thermostat
+		if (domain->severalThermostats()) {
+			global_log->error() << "LeapfrogHip: component-wise thermostats are not available on the device path" << std::endl;
+			Simulation::exit(685);
+		}
+		if ((rc = ls1hip_scale_velocities(ctx, domain->getGlobalBetaTrans(), domain->getGlobalBetaRot()))) {
+			global_log->error() << "ls1hip_scale_velocities: " << ls1hip_last_error(ctx) << std::endl;
+			Simulation::exit(686);
+		}
+	}
+	// transition3to1 + transition1to2: FullMolecule::upd_preF for every owned molecule (Leapfrog.cpp:48-64)
+	if ((rc = ls1hip_kick_drift(ctx, _timestepLength))) {
+		global_log->error() << "ls1hip_kick_drift: " << ls1hip_last_error(ctx) << std::endl;
+		Simulation::exit(687);
+	}
+	cont->deviceAdvanced();
+	_state = STATE_PRE_FORCE_CALCULATION;
+}
+
+void LeapfrogHip::eventForcesCalculated(ParticleContainer* moleculeContainer, Domain* domain) {
+	if (_state != STATE_PRE_FORCE_CALCULATION) return;
+	LinkedCellsHip* cont = device_container(moleculeContainer);
+	ls1hip_ctx* ctx = cont->context();
+	double summv2 = 0., sumIw2 = 0.;
+	uint64_t n = 0, rotdof = 0;
+	// transition2to3: upd_postF + the kinetic sums of thermostat 0 (Leapfrog.cpp:66-150)
+	int rc = ls1hip_kick(ctx, 0.5 * _timestepLength, &summv2, &sumIw2, &n, &rotdof);
+	if (rc) {
+		global_log->error() << "ls1hip_kick: " << ls1hip_last_error(ctx) << std::endl;
+		Simulation::exit(688);
+	}
+	domain->setLocalSummv2(summv2, 0);
+	domain->setLocalSumIw2(sumIw2, 0);
+	domain->setLocalNrotDOF(0, n, rotdof);
+	_haveBeta = true;
+	_state = STATE_POST_FORCE_CALCULATION;
+	++_stepsDone;
+	// lazily synced mirror: after the last step (final checkpoint, finishing plugins) and every N steps on request
+	long interval = 0;
+	if (const char* e = getenv("LS1HIP_MIRROR_SYNC_INTERVAL")) interval = atol(e);
+	Simulation* sim = global_simulation;
+	bool last = sim->getSimulationStep() >= sim->getNumTimesteps();
+	if (const char* e = getenv("LS1HIP_MIRROR_SYNC_FINAL"))  // "0": nothing will iterate the molecules after the run (no final
+		if (atoi(e) == 0) last = false;                      // checkpoint, no finishing plugin): skip the O(N) host refill
+	if (last || (interval > 0 && _stepsDone % (unsigned long)interval == 0)) cont->syncMirrorFromDevice();
+}

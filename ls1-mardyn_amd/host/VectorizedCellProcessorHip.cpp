@@ -33,6 +33,7 @@
 #include "utils/Logger.h"
 
 #include "ls1hip.h"
+#include "ls1hip_components.hpp"
 
 using Log::global_log;
 
@@ -63,37 +64,7 @@ VectorizedCellProcessor::VectorizedCellProcessor(Domain& domain, double cutoffRa
 	int rc = ls1hip_create(device, &st.ctx);
 	if (rc) die(nullptr, "ls1hip_create", rc);
 	// component set -> flat tables of the C ABI (same columns as the .inp component block)
-	const std::vector<Component>& comps = *(_simulation.getEnsemble()->getComponents());
-	const int nc = (int)comps.size();
-	std::vector<int> nlj(nc), nch(nc), nd(nc), nq(nc);
-	std::vector<double> lj, ch, dp, qp, mass(nc), I(3 * nc);
-	for (int k = 0; k < nc; ++k) {
-		const Component& c = comps[k];
-		nlj[k] = c.numLJcenters(); nch[k] = c.numCharges(); nd[k] = c.numDipoles(); nq[k] = c.numQuadrupoles();
-		for (unsigned s = 0; s < c.numLJcenters(); ++s) {
-			const LJcenter& a = c.ljcenter(s);
-			for (double v : {a.rx(), a.ry(), a.rz(), a.m(), a.eps(), a.sigma(), a.shift6()}) lj.push_back(v);
-		}
-		for (unsigned s = 0; s < c.numCharges(); ++s) {
-			const Charge& a = c.charge(s);
-			for (double v : {a.rx(), a.ry(), a.rz(), a.m(), a.q()}) ch.push_back(v);
-		}
-		for (unsigned s = 0; s < c.numDipoles(); ++s) {
-			const Dipole& a = c.dipole(s);
-			for (double v : {a.rx(), a.ry(), a.rz(), a.ex(), a.ey(), a.ez(), a.absMy()}) dp.push_back(v);
-		}
-		for (unsigned s = 0; s < c.numQuadrupoles(); ++s) {
-			const Quadrupole& a = c.quadrupole(s);
-			for (double v : {a.rx(), a.ry(), a.rz(), a.ex(), a.ey(), a.ez(), a.absQ()}) qp.push_back(v);
-		}
-		mass[k] = c.m();
-		I[3 * k] = c.I11(); I[3 * k + 1] = c.I22(); I[3 * k + 2] = c.I33();
-	}
-	std::vector<double> mix = domain.getmixcoeff();
-	mix.resize((size_t)nc * (nc - 1), 0.0);  // (xi, eta) per unordered pair
-	rc = ls1hip_set_components(st.ctx, nc, nlj.data(), nch.data(), nd.data(), nq.data(), lj.data(), ch.data(), dp.data(),
-							   qp.data(), mass.data(), I.data(), mix.data(), domain.getepsilonRF(), cutoffRadius,
-							   LJcutoffRadius);
+	rc = ls1hip_set_components_from(st.ctx, *(_simulation.getEnsemble()->getComponents()), domain, cutoffRadius, LJcutoffRadius);
 	if (rc) die(st.ctx, "ls1hip_set_components", rc);
 	_numThreads = 0;
 	std::lock_guard<std::mutex> lk(g_mu);

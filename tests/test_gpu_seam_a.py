@@ -54,9 +54,9 @@ ETHANE = ('<moleculetype id="1" name="C2H6">'
           '</moleculetype>')
 
 
-def _run(binary, cfg, cwd, steps):
+def _run(binary, cfg, cwd, steps, final_checkpoint=0):
     env = dict(os.environ, OMP_NUM_THREADS="8")
-    out = subprocess.run([binary, cfg, "--steps", str(steps), "--final-checkpoint=0"], cwd=cwd, env=env,
+    out = subprocess.run([binary, cfg, "--steps", str(steps), f"--final-checkpoint={final_checkpoint}"], cwd=cwd, env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     rows = re.findall(r"Simstep = (\d+)\s+T = (\S+)\s+U_pot = (\S+)\s+p = (\S+)", out.stdout)
@@ -64,8 +64,13 @@ def _run(binary, cfg, cwd, steps):
     return np.array([[float(x) for x in r[1:]] for r in rows]), out.stdout
 
 
+ARGON = ('<moleculetype id="1" name="Argon"><site type="LJ126" id="1"><coords><x>0.0</x><y>0.0</y><z>0.0</z></coords>'
+         '<mass>0.039948</mass><sigma>6.4160007</sigma><epsilon>0.000369852537</epsilon><shifted>0</shifted></site>'
+         '<momentsofinertia rotaxes="xyz"><Ixx>0.0</Ixx><Iyy>0.0</Iyy><Izz>0.0</Izz></momentsofinertia></moleculetype>')
+
+
 @pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(HIP)), reason="oracle/_ref binaries not built")
-@pytest.mark.parametrize("case", ["1clj_generated", "ethane_inp"])
+@pytest.mark.parametrize("case", ["1clj_generated", "ethane_inp", "argon_example"])
 def test_reference_driver_with_hip_cell_processor(tmp_path, case):
     if case == "1clj_generated":
         N = 2 * 14 ** 3
@@ -74,6 +79,16 @@ def test_reference_driver_with_hip_cell_processor(tmp_path, case):
                           phasespace='<generator name="CubicGridGenerator"><specification>density</specification>'
                                      '<density>0.785302672</density><binaryMixture>false</binaryMixture></generator>')
         steps = 10
+    elif case == "argon_example":
+        # BASELINE.json configs[0] (plumbing): the reference's shipped example examples/Argon/200K_18mol_l — its phase space
+        # file (copied as a fixture), its component, box, time step, temperature and cutoff (r_c = 5.15 sigma, 3 cells per
+        # dimension) from its config.xml, output plugins stripped as in BASELINE.md; NVT (velocity scaling) as shipped.
+        with gzip.open(os.path.join(GOLDEN, "inputs", "Argon_200K_18mol_l.inp.gz"), "rb") as fi, \
+                open(tmp_path / "Argon_200K_18mol_l.inp", "wb") as fo:
+            shutil.copyfileobj(fi, fo)
+        cfg = HEAD.format(dt=0.0667516, steps=20, temp=0.000633363365, L="108.43455", rc=33.0702, components=ARGON,
+                          phasespace='<file type="ASCII">Argon_200K_18mol_l.inp</file>')
+        steps = 20
     else:
         with gzip.open(os.path.join(GOLDEN, "inputs", "Ethan_equilibrated.inp.gz"), "rb") as fi, \
                 open(tmp_path / "ethan.inp", "wb") as fo:

@@ -1,0 +1,119 @@
+"""Seam-B drop-in proof on the GPU box: the REAL reference driver with the DEVICE-RESIDENT container and integrator.
+
+oracle/_ref/MarDyn_hipB = every reference source compiled unmodified (Simulation.cpp with the force-included registration
+header ls1-mardyn_amd/host/seam_b_register.h) + ls1-mardyn_amd/host/LinkedCellsHip.cpp (`class LinkedCellsHip : public
+ParticleContainer`, `class LeapfrogHip : public Integrator`) + libls1hip.  The molecules live on the GPU for the whole
+run; per step the driver's own loop (Simulation::simulate) calls update / updateMoleculeCaches / traverseCells /
+eventNewTimestep / eventForcesCalculated on those classes.  It must print the same per-step T / U_pot / p as the
+unmodified reference binary, and its final checkpoint (written by the reference's own writer from the lazily synced host
+mirror) must hold the same molecules."""
+import gzip
+import os
+import re
+import shutil
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_pkg
+from golden_io import GOLDEN
+from test_gpu_seam_a import ARGON, ETHANE, HEAD, LJ1, REF, _run
+
+pytestmark = pytest.mark.gpu
+
+HIPB = os.path.join(ROOT, "oracle", "_ref", "MarDyn_hipB")
+inp = load_pkg("inp")
+
+
+def _restart_records(path):
+    """molecule lines of the reference's ASCII restart file (Domain::writeCheckpoint -> ICRVQD lines)"""
+    rows = {}
+    with open(path) as fh:
+        body = False
+        for ln in fh:
+            if ln.strip().startswith("MoleculeFormat"):
+                body = True
+                continue
+            if body and ln.strip():
+                t = ln.split()
+                rows[int(t[0])] = np.array([float(x) for x in t[2:15]])
+    return rows
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(HIPB)), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("case", ["1clj_generated", "ethane_inp", "argon_example"])
+def test_reference_driver_with_device_container_and_integrator(tmp_path, case):
+    if case == "1clj_generated":
+        N = 2 * 50 ** 3  # 250 000 molecules from the reference's own CubicGridGenerator (-> initCubicGrid on the mirror)
+        L = (N / 0.785302672) ** (1 / 3)
+        cfg = HEAD.format(dt=0.002, steps=20, temp=0.95, L=repr(L), rc=2.5, components=LJ1,
+                          phasespace='<generator name="CubicGridGenerator"><specification>density</specification>'
+                                     '<density>0.785302672</density><binaryMixture>false</binaryMixture></generator>')
+        steps = 20
+    elif case == "argon_example":
+        with gzip.open(os.path.join(GOLDEN, "inputs", "Argon_200K_18mol_l.inp.gz"), "rb") as fi, \
+                open(tmp_path / "Argon_200K_18mol_l.inp", "wb") as fo:
+            shutil.copyfileobj(fi, fo)
+        cfg = HEAD.format(dt=0.0667516, steps=20, temp=0.000633363365, L="108.43455", rc=33.0702, components=ARGON,
+                          phasespace='<file type="ASCII">Argon_200K_18mol_l.inp</file>')
+        steps = 20
+    else:
+        with gzip.open(os.path.join(GOLDEN, "inputs", "Ethan_equilibrated.inp.gz"), "rb") as fi, \
+                open(tmp_path / "ethan.inp", "wb") as fo:
+            shutil.copyfileobj(fi, fo)
+        cfg = HEAD.format(dt=0.5, steps=5, temp=0.000855, L="571.607759", rc=32.1254, components=ETHANE,
+                          phasespace='<file type="ASCII">ethan.inp</file>')
+        steps = 5
+    out = {}
+    for tag, binary in (("ref", REF), ("hipB", HIPB)):
+        d = tmp_path / tag
+        d.mkdir()
+        for f in os.listdir(tmp_path):
+            if f.endswith(".inp"):
+                shutil.copy(tmp_path / f, d / f)
+        (d / "config.xml").write_text(cfg)
+        rows, log = _run(binary, "config.xml", str(d), steps, final_checkpoint=1)
+        speed = re.search(r"Simulation speed:\s*([0-9.eE+-]+)", log)
+        out[tag] = (rows, log, float(speed.group(1)) if speed else float("nan"), d)
+    ref, hip = out["ref"][0], out["hipB"][0]
+    assert "LinkedCellsHip: device-resident container" in out["hipB"][1] and "LeapfrogHip" in out["hipB"][1]
+    n = min(len(ref), len(hip))
+    assert n >= steps
+    # the driver prints 6 significant digits
+    assert np.allclose(hip[:n], ref[:n], rtol=2e-5, atol=1e-12), (ref[:n], hip[:n])
+    # final checkpoint: written by the reference's writer iterating OUR container (mirror synced from the device)
+    fr = [f for f in os.listdir(out["ref"][3]) if f.endswith(".restart.dat")]
+    fh = [f for f in os.listdir(out["hipB"][3]) if f.endswith(".restart.dat")]
+    assert fr and fh
+    a, b = _restart_records(out["ref"][3] / fr[0]), _restart_records(out["hipB"][3] / fh[0])
+    assert a.keys() == b.keys() and len(a) > 0
+    ids = sorted(a)
+    A, B = np.array([a[i] for i in ids]), np.array([b[i] for i in ids])
+    Lbox = float(re.search(r"<lx>([^<]+)</lx>", cfg).group(1))
+    dr = A[:, :3] - B[:, :3]
+    dr -= Lbox * np.round(dr / Lbox)
+    assert np.max(np.abs(dr)) < 1e-7 * Lbox
+    assert np.max(np.abs(A[:, 3:6] - B[:, 3:6])) < 1e-6 * max(np.max(np.abs(A[:, 3:6])), 1e-300)
+    print(f"[seam B {case}] Simulation speed: reference {out['ref'][2]:.4g}  device container {out['hipB'][2]:.4g} molecule-updates/s")
+
+
+@pytest.mark.skipif(not os.path.exists(HIPB), reason="oracle/_ref binaries not built")
+def test_device_container_speed_line_in_the_reference_driver(tmp_path):
+    """The reference's own `Simulation speed` line (MarDyn.cpp:253-266) with the device container at a size where the
+    per-run host work (generator, initial upload, final mirror sync) no longer dominates: N = 2*100^3, 100 steps, NVT as
+    every shipped config.  The per-step path of this seam is the piecewise one (kick-drift, re-bin, halo, forces, kick with
+    the driver's host-side global values in between); the fused / list-reuse loop needs the loop handed over (ls1hip_run)."""
+    N = 2 * 100 ** 3
+    L = (N / 0.785302672) ** (1 / 3)
+    cfg = HEAD.format(dt=0.002, steps=100, temp=0.95, L=repr(L), rc=2.5, components=LJ1,
+                      phasespace='<generator name="CubicGridGenerator"><specification>density</specification>'
+                                 '<density>0.785302672</density><binaryMixture>false</binaryMixture></generator>')
+    (tmp_path / "config.xml").write_text(cfg)
+    os.environ["LS1HIP_MIRROR_SYNC_FINAL"] = "0"  # --final-checkpoint=0 and no plugins: nobody iterates after the run
+    try:
+        rows, log = _run(HIPB, "config.xml", str(tmp_path), 100)
+    finally:
+        del os.environ["LS1HIP_MIRROR_SYNC_FINAL"]
+    speed = float(re.search(r"Simulation speed:\s*([0-9.eE+-]+)", log).group(1))
+    print(f"[seam B] N={N}: Simulation speed {speed:.4g} molecule-updates/s (reference driver, device container)")
+    assert np.all(np.isfinite(rows)) and speed > 5e7

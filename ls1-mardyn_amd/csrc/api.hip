@@ -32,6 +32,15 @@ static thread_local std::string g_create_err = "";
 	} while (0)
 
 // ---- timing --------------------------------------------------------------------------------------------------------
+constexpr size_t TIMER_MAX_PENDING = 4096;  // event pairs kept before they are folded into the total (bounds the event pool)
+static void timer_fold(Timer& t) {
+	for (size_t i = 0; i + 1 < t.used; i += 2) {
+		float ms = 0.f;
+		hipEventSynchronize(t.ev[i + 1]);
+		if (hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]) == hipSuccess) t.total_ms += ms;
+	}
+	t.used = 0;
+}
 struct TimedScope {
 	ls1hip_ctx* c;
 	Timer* t;
@@ -39,6 +48,7 @@ struct TimedScope {
 	hipStream_t s;
 	TimedScope(ls1hip_ctx* ctx, Timer& tm, hipStream_t stream = nullptr) : c(ctx), t(&tm), s(stream ? stream : ctx->stream) {
 		if (!c->timing_on || (c->timing_on == 2 && t != &c->t_force)) return;
+		if (t->used >= TIMER_MAX_PENDING) timer_fold(*t);  // long runs with timing on: fold the finished pairs, reuse the events
 		if (t->used + 2 > t->ev.size()) {
 			hipEvent_t a, b;
 			if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
@@ -55,14 +65,7 @@ struct TimedScope {
 	}
 };
 
-static void timer_collect(Timer& t) {
-	for (size_t i = 0; i + 1 < t.used; i += 2) {
-		float ms = 0.f;
-		hipEventSynchronize(t.ev[i + 1]);
-		if (hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]) == hipSuccess) t.total_ms += ms;
-	}
-	t.used = 0;
-}
+static void timer_collect(Timer& t) { timer_fold(t); }
 static void timer_free(Timer& t) {
 	for (auto e : t.ev) hipEventDestroy(e);
 	t.ev.clear();

@@ -322,9 +322,17 @@ __global__ void __launch_bounds__(TPB) k_leave_import(RebinArgs a, const double*
 	const uint32_t p = at + i;
 	a.src.id[p] = (uint64_t)__double_as_longlong(r[0]);
 	a.src.cid[p] = (int32_t)__double_as_longlong(r[1]);
-	a.src.x[p] = r[2];
-	a.src.y[p] = r[3];
-	a.src.z[p] = r[4];
+	// The sender shifted the position into this rank's frame (r + shift across a periodic face): x = -tiny + L rounds to
+	// exactly L = bmax, outside [bmin, bmax).  Same rounding clamps as the local wrap (DomainDecompBase.cpp:206-219): an
+	// immigrant is by construction owned by this rank, so it is pulled onto the box.
+	double rin[3] = {r[2], r[3], r[4]};
+	for (int d = 0; d < 3; ++d) {
+		if (rin[d] < a.g.bmin[d]) rin[d] = a.g.bmin[d];
+		if (rin[d] >= a.g.bmax[d]) rin[d] = next_toward_down(a.g.bmax[d]);
+	}
+	a.src.x[p] = rin[0];
+	a.src.y[p] = rin[1];
+	a.src.z[p] = rin[2];
 	a.src.vx[p] = r[5];
 	a.src.vy[p] = r[6];
 	a.src.vz[p] = r[7];
@@ -338,9 +346,9 @@ __global__ void __launch_bounds__(TPB) k_leave_import(RebinArgs a, const double*
 		a.src.Dz[p] = r[14];
 	}
 	// bin on arrival (same rule as k_classify for a molecule inside the box)
-	const int cx = cell_coord_owned(a.g, 0, r[2]);
-	const int cy = cell_coord_owned(a.g, 1, r[3]);
-	const int cz = cell_coord_owned(a.g, 2, r[4]);
+	const int cx = cell_coord_owned(a.g, 0, rin[0]);
+	const int cy = cell_coord_owned(a.g, 1, rin[1]);
+	const int cz = cell_coord_owned(a.g, 2, rin[2]);
 	const uint32_t key = (uint32_t)cell_index(a.g, cx, cy, cz);
 	a.key[p] = key;
 	a.rank[p] = cell_counter_add(a.count, key);

@@ -27,6 +27,11 @@ LEAVING, HALO = 0, 1
 RECORD_DOUBLES = {LEAVING: 15, HALO: 9}
 
 
+class DecompositionError(RuntimeError):
+    """Raised on EVERY rank when any rank's engine reported an error during an exchange (capacity overflow, lost
+    molecule ...): an error raised on one rank only would leave the others blocked in the next collective."""
+
+
 def dims_create(world: int):
     """Balanced 3-D factorisation, largest factor first (what MPI_Dims_create returns for 1, 2, 4, 8, ...)."""
     dims = [1, 1, 1]
@@ -141,6 +146,7 @@ class HaloExchanger:
         self._comm_stream = None
         self.meta_group = None
         self.force_count_exchange = False  # diagnostics: run the count all_gather even with one rank
+        self._deferred = None  # engine error caught on this rank, reported collectively with the next count exchange
         if not self.stage and decomp.world > 1 and os.environ.get("LS1_COUNTS_TRANSPORT", "nccl") == "gloo":
             self.meta_group = dist.new_group(backend="gloo")
 
@@ -160,7 +166,7 @@ class HaloExchanger:
         return self._comm_stream
 
     def _gather_counts(self, counts):
-        """[world, 27] int64 table of every rank's export counts"""
+        """[world, len(counts)] int64 table of every rank's export counts (+ status column)"""
         torch, dist = self._torch, self.dist
         if self.dc.world == 1 and not self.force_count_exchange:
             return counts[None, :]
@@ -177,7 +183,7 @@ class HaloExchanger:
         st = self._side_stream()
         with torch.cuda.stream(st):
             mine = torch.from_numpy(counts).to(self.device, non_blocking=True)
-            out = torch.empty((self.dc.world, 27), dtype=torch.int64, device=self.device)
+            out = torch.empty((self.dc.world, len(counts)), dtype=torch.int64, device=self.device)
             dist.all_gather_into_tensor(out, mine, group=self.group)
             host = out.to("cpu", non_blocking=True)
             st.synchronize()
@@ -191,9 +197,24 @@ class HaloExchanger:
         and receives have been posted and before they are waited for (inner-cell force launch goes here)."""
         torch, dist = self._torch, self.dist
         w = RECORD_DOUBLES[kind]
-        counts = self.engine.export_counts(kind).astype(np.int64)  # [27]
+        # Error handling is COLLECTIVE: the count table carries a status column.  An engine error on this rank (export /
+        # halo capacity overflow, a molecule beyond the halo region — raised by export_counts / import_done) is not thrown
+        # here but gathered, and every rank raises after the all_gather, before any point-to-point operation is posted.
+        try:
+            counts = self.engine.export_counts(kind).astype(np.int64)  # [27]
+        except Exception as e:  # noqa: BLE001 (any engine failure must reach the other ranks)
+            self._deferred = self._deferred or e
+            counts = np.zeros(27, dtype=np.int64)
+        status = np.int64(1 if self._deferred is not None else 0)
         if self.peers:
-            allc = self._gather_counts(counts)
+            table = self._gather_counts(np.concatenate([counts, [status]]))
+            allc, stat = table[:, :27], table[:, 27]
+            if np.any(stat != 0):
+                bad = [int(r) for r in np.nonzero(stat)[0]]
+                mine = f"; this rank: {self._deferred}" if self._deferred is not None else ""
+                raise DecompositionError(f"rank(s) {bad} reported an engine error during the exchange of kind {kind}{mine}")
+        elif self._deferred is not None:
+            raise self._deferred
         # ONE device buffer holds every outgoing message (directions grouped by peer) and ONE every incoming message:
         # one pack call / one import call / one stream synchronisation per exchange, whatever the number of peers
         n_out = {p: int(sum(counts[d] for d in self._outgoing[p])) for p in self.peers}
@@ -253,7 +274,12 @@ class HaloExchanger:
             if self.stage:
                 rbuf = rbuf.to(self.device)
             self.engine.import_records(kind, self._ptr(rbuf), tot_in)  # asynchronous: rbuf lives until import_done
-        self.engine.import_done(kind)
+        try:
+            self.engine.import_done(kind)
+        except Exception as e:  # noqa: BLE001: reported by all ranks together at the next count exchange
+            if not self.peers:
+                raise
+            self._deferred = self._deferred or e
         del sbuf, rbuf
 
 
@@ -330,12 +356,17 @@ class DistributedSimulation:
         return out
 
     def reduce_globals(self, macro, kin):
-        """Domain::calculateGlobalValues: one all_reduce of {U_pot, virial, sum mv^2, sum Iw^2, N, rotDOF}."""
+        """Domain::calculateGlobalValues: one all_reduce of {U_pot, virial, sum mv^2, sum Iw^2, N, rotDOF} (+ the error
+        status of the last import of this rank, so that a deferred engine error ends the run on every rank)."""
         torch = self._torch
-        t = torch.tensor([macro[0], macro[1], kin[0], kin[1], float(kin[2]), float(kin[3])], dtype=torch.float64,
+        err = 1.0 if self.ex._deferred is not None else 0.0
+        t = torch.tensor([macro[0], macro[1], kin[0], kin[1], float(kin[2]), float(kin[3]), err], dtype=torch.float64,
                          device="cpu" if self.stage else self.device)
         self.dist.all_reduce(t, group=self.group)
         v = t.cpu().numpy()
+        if v[6] != 0:
+            mine = f"; this rank: {self.ex._deferred}" if self.ex._deferred is not None else ""
+            raise DecompositionError(f"{int(v[6])} rank(s) reported an engine error in the last exchange{mine}")
         return dict(upot=float(v[0]), virial=float(v[1]), summv2=float(v[2]), sumIw2=float(v[3]), n=int(v[4]),
                     rot_dof=int(v[5]))
 

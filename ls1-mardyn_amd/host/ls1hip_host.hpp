@@ -118,6 +118,10 @@ public:
 									t.I.data(), p(t.mix) ? p(t.mix) : zero, t.eps_rf, cutoffRadius,
 									LJCutoffRadius > 0. ? LJCutoffRadius : cutoffRadius));
 		check(ls1hip_set_option(_ctx, "cells_in_cutoff", cellsInCutoffRadius));
+		// The engine's global box has its origin at 0 (ls1hip_set_domain); the sequential driver's box does too
+		// (Domain / DomainDecompBase).  A shifted box would silently move the frame of every uploaded coordinate.
+		for (int d = 0; d < 3; ++d)
+			if (bBoxMin[d] != 0.) throw Error(LS1HIP_EINVAL, "LinkedCells: the bounding box must start at the origin");
 		double len[3], lo[3], hi[3];
 		for (int d = 0; d < 3; ++d) {
 			len[d] = bBoxMax[d] - bBoxMin[d];

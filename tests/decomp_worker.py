@@ -27,6 +27,18 @@ def main():
     mine = np.all((r >= lo) & (r < hi), axis=1)
     eng = CpuEngine(L, lo, hi, rank, dc.neighbor_table(), rc)
     eng.upload(ids[mine], r[mine], v[mine])
+    fail = os.environ.get("LS1_TEST_FAIL", "")  # "<rank>:<export_counts call number>:<export|import>"
+    if fail and int(fail.split(":")[0]) == rank:
+        at, where = int(fail.split(":")[1]), fail.split(":")[2]
+        name = "export_counts" if where == "export" else "import_done"
+        orig, calls = getattr(eng, name), [0]
+
+        def failing(*a, **k):
+            calls[0] += 1
+            if calls[0] == at:
+                raise RuntimeError(f"injected engine failure in {name} on rank {rank}")
+            return orig(*a, **k)
+        setattr(eng, name, failing)
     sim = decomp.DistributedSimulation(dc, eng, dist, torch.device("cpu"))
     macro0 = sim.initial_forces()
     g0 = sim.reduce_globals(macro0, (0.0, 0.0, len(eng.ids), 0))

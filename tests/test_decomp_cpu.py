@@ -123,3 +123,24 @@ def test_gloo_world_matches_single_domain_oracle(world, grid):
         assert abs(z["upot"] - o["upot"]) < 1e-9 * abs(o["upot"])
         assert abs(z["summv2"] - o["summv2"]) < 1e-10 * o["summv2"]
         assert int(z["n"]) == len(ids)
+
+
+@pytest.mark.parametrize("where", ["export", "import"])
+def test_engine_error_on_one_rank_fails_every_rank_without_hanging(where):
+    """error handling must be collective.  One rank's engine fails (capacity overflow / lost molecule are raised
+    by export_counts / import_done); every rank must leave with DecompositionError instead of blocking in the next
+    all_gather / irecv."""
+    L, r, v = _liquid(5)
+    ids = np.arange(1, len(r) + 1, dtype=np.uint64)
+    with tempfile.TemporaryDirectory() as td:
+        inp_path = os.path.join(td, "in.npz")
+        np.savez(inp_path, L=L, r=r, v=v, ids=ids, rc=1.8)
+        env = dict(os.environ, LS1_TEST_INPUT=inp_path, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", LS1_TEST_LOOPBACK="0",
+                   LS1_TEST_FAIL=f"1:5:{where}")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+               os.path.join(ROOT, "tests", "decomp_worker.py"), os.path.join(td, "out.npz"), "4", "0.004", "2x1x1"]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120)  # a hang would hit the timeout
+        assert res.returncode != 0
+        assert res.stderr.count("DecompositionError") >= 2, res.stderr[-3000:]
+        assert "injected engine failure" in res.stderr

@@ -335,3 +335,43 @@ def test_random_decompositions_equal_single_domain(seed):
     dr -= L * np.round(dr / L)
     assert np.max(np.abs(dr)) < 1e-10
     assert np.max(np.abs(a1["v"] - b1["v"])) < 1e-10 * np.max(np.abs(a1["v"]))
+
+
+def test_leaver_through_a_periodic_face_lands_inside_the_receiver():
+    """a molecule that leaves through the global low face at x = -tiny arrives on the far rank at x + L, which
+    rounds to exactly L = the receiver's bmax — outside [bmin, bmax).  The import clamps it onto the box (the rounding rule
+    of the local wrap, DomainDecompBase.cpp:206-219); without it the next halo generation reported a lost molecule.  Same at
+    x = L - tiny leaving upwards (arrives at exactly 0 - handled by the lower clamp)."""
+    L, r, v = _liquid(12)
+    rc, dt = 2.5, 0.004
+    v = v * 0.0
+    r = r.copy()
+    # two molecules a hair inside the global faces, moving out by less than the rounding granularity of L
+    r[0] = [1e-17, 0.3 * L[1], 0.4 * L[2]]
+    v[0] = [-2e-17 / dt, 0.0, 0.0]
+    r[1] = [np.nextafter(L[0], 0.0), 0.6 * L[1], 0.2 * L[2]]
+    v[1] = [1e-3, 0.0, 0.0]
+    keep = np.ones(len(r), bool)  # drop neighbours that sit on top of the two probes
+    for p in (0, 1):
+        d = r - r[p]
+        d -= L * np.round(d / L)
+        keep &= (np.linalg.norm(d, axis=1) > 0.8) | (np.arange(len(r)) == p)
+    r, v = r[keep], v[keep]
+    ids = np.arange(1, len(r) + 1, dtype=np.uint64)
+    comps = inp.ComponentSet([inp.make_component(lj=[(0, 0, 0, 1, 1, 1, rc, 0)])], np.zeros((0, 2)), 1e10)
+    single = InProcessCluster(1, comps, rc, L, ids, r, v)
+    multi = InProcessCluster(2, comps, rc, L, ids, r, v, (2, 1, 1))
+    single.forces(split=False)
+    multi.forces()
+    for _ in range(3):
+        t1, _k = single.step(dt)
+        tm, _k = multi.step(dt)  # raised LS1HIP_ELOST before the clamp
+    a, b = single.gather(), multi.gather()
+    assert np.array_equal(a["ids"], b["ids"])
+    dr = a["r"] - b["r"]
+    dr -= L * np.round(dr / L)
+    assert np.max(np.abs(dr)) < 1e-11
+    assert np.max(np.abs(a["F"] - b["F"])) < 1e-11 * np.max(np.abs(a["F"]))
+    assert np.allclose(t1, tm, rtol=1e-11)
+    for e in single.eng + multi.eng:
+        e.close()

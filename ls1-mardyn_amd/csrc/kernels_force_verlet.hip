@@ -40,6 +40,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace ls1 {
 
@@ -390,12 +391,23 @@ __device__ __forceinline__ void stage_positions(const ForceParams& P, const Bric
 }
 
 // ---- BUILD ------------------------------------------------------------------------------------------------------------
+// The list only has to be a SUPERSET of the pairs within rc + skin (the force pass re-tests every entry exactly in FP64),
+// so the search runs in FP32 on brick-relative coordinates with a conservative threshold: packed FP32 arithmetic handles
+// two candidates per instruction (v_pk_add / v_pk_mul / v_pk_fma_f32: 3 VALU per candidate instead of 6 FP64), the staged
+// region shrinks to 12 B per molecule (34 KB: the search kernel is not LDS-capacity bound) and its LDS reads halve.
+// Per candidate the bookkeeping is: compare, add-with-carry into the count, slot address (and-or), one ds_write_b16.
+// FP32 slack: coordinates are relative to the region's low corner (< 6 cell lengths), |r^2_fp32 - r^2| <= 2 (|dx| + |dy| +
+// |dz|) ulp(extent) + 3 ulp(r^2) ~ 4e-5 at liquid-argon scale; the threshold adds 2e-6 * extent * (rc + skin) + 1e-5 (rc +
+// skin)^2, several times that bound.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef f32x2 f32x2_a4 __attribute__((aligned(4)));  // candidate pairs start at any molecule index: ds_read2_b32, not b64
+
 __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int nbx, int nby, int nbz) {
 	constexpr int NT = VNT, RX = VRX, RY = VRY, BX = VBX, BY = VBY, NBC = VNBC, CAPS = VCAPS;
-	__shared__ double spos[3 * CAPS];
-	double* const sx = spos;
-	double* const sy = spos + CAPS;
-	double* const sz = spos + 2 * CAPS;
+	__shared__ float fpos[3 * CAPS];
+	float* const fx = fpos;
+	float* const fy = fpos + CAPS;
+	float* const fz = fpos + 2 * CAPS;
 	__shared__ uint32_t cstart[VNRC + 1];
 	__shared__ uint32_t gbeg[VNRC];
 	__shared__ uint32_t bstart[NBC + 1];
@@ -408,10 +420,28 @@ __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int n
 	block_tables(P, bs, T, wsum);
 	const uint32_t total = cstart[VNRC], n_i = bstart[NBC];
 	if (total > (uint32_t)VCAPJ) return;  // unstaged brick: evaluated directly every step, no lists
-	stage_positions(P, T, sx, sy, sz);
+	// brick-relative FP32 positions (origin = low corner of the region's first cell)
+	const double ox = P.g.bmin[0] + (double)(bs.x0 - 2) * P.g.clen[0];
+	const double oy = P.g.bmin[1] + (double)(bs.y0 - 2) * P.g.clen[1];
+	const double oz = P.g.bmin[2] + (double)(bs.z0 - 2) * P.g.clen[2];
+	for (int c = tid >> 4; c < VNRC; c += NT / 16) {
+		const uint32_t n = cstart[c + 1] - cstart[c], s0 = cstart[c], g0 = gbeg[c];
+		for (uint32_t k = (uint32_t)tid & 15u; k < n; k += 16u) {
+			fx[s0 + k] = (float)(P.x[g0 + k] - ox);
+			fy[s0 + k] = (float)(P.y[g0 + k] - oy);
+			fz[s0 + k] = (float)(P.z[g0 + k] - oz);
+		}
+	}
+	if (tid < 8) {
+		fx[total + tid] = 1.0e18f;  // far-away padding behind the last molecule (r^2 ~ 1e36, finite)
+		fy[total + tid] = 1.0e18f;
+		fz[total + tid] = 1.0e18f;
+	}
 	__syncthreads();
 	const uint64_t dummy = (uint64_t)(total * 8u) * 0x0001000100010001ull;  // four entries pointing at the far-away slot
-	const double rcs2 = P.vl_rc2;
+	const float ext = (float)fmax(fmax(RX * P.g.clen[0], RY * P.g.clen[1]), VRZ * P.g.clen[2]);
+	const float rcs = (float)sqrt(P.vl_rc2);
+	const float thr = (float)P.vl_rc2 * (1.0f + 1e-5f) + 2e-6f * ext * rcs;
 	for (uint32_t base = 0, pass = 0; base < n_i; base += NT, ++pass) {
 		const uint32_t it = base + (uint32_t)tid;
 		const bool active = it < n_i;
@@ -431,44 +461,66 @@ __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int n
 			const int rcell = ((cz + 1) * RY + (cy + 1)) * RX + (cx + 1);
 			const uint32_t ii = cstart[rcell] + (it - bstart[lo]);
 			const int rowbase = (cz * RY + cy) * RX + cx;
-			const double xi = sx[ii], yi = sy[ii], zi = sz[ii];
-			char* const wb = reinterpret_cast<char*>(win) + tid * 2;  // slot s of this lane: wb + s * NT * 2
-			// 9 contiguous candidate rows per molecule, exact FP64 distance test with rc + skin
-			for (int row = 0; row < 9; ++row) {
+			const f32x2 xi = {fx[ii], fx[ii]}, yi = {fy[ii], fy[ii]}, zi = {fz[ii], fz[ii]};
+			const uint32_t wb = (uint32_t)tid * 2u;  // byte offset of this lane inside a window row (rows of NT * 2 = 1024 B)
+			char* const winb = reinterpret_cast<char*>(win);
+			// one candidate: unconditional store of its offset at slot cnt & 7, cnt advances on a hit (a miss is overwritten)
+			auto put = [&](uint32_t j, bool hit) {
+				*reinterpret_cast<uint16_t*>(winb + (((cnt << 10) & 0x1c00u) | wb)) = (uint16_t)(j * 8u);
+				cnt += hit ? 1u : 0u;
+			};
+			auto flush = [&](uint32_t before) {
+				if ((cnt >> 2) != (before >> 2)) {  // a word of four entries is complete
+					const uint32_t w = before >> 2;
+					const char* const s0 = winb + ((w & 1u) * 4096u + wb);
+					const uint64_t e0 = *reinterpret_cast<const uint16_t*>(s0), e1 = *reinterpret_cast<const uint16_t*>(s0 + 1024),
+								   e2 = *reinterpret_cast<const uint16_t*>(s0 + 2048), e3 = *reinterpret_cast<const uint16_t*>(s0 + 3072);
+					if (w < (uint32_t)VMAXW) wp[(size_t)w * 64] = e0 | (e1 << 16) | (e2 << 32) | (e3 << 48);
+				}
+			};
+			// SELF: the molecule itself lives in the middle row only — the other eight rows skip the index test
+			auto scan_row = [&](int row, auto self_tag) {
+				constexpr bool SELF = decltype(self_tag)::value;
 				const int r0 = rowbase + (row / 3) * (RY * RX) + (row % 3) * RX;
 				const uint32_t jb = cstart[r0], je = cstart[r0 + 3];
-				const uint32_t self = row == 4 ? ii : 0xffffffffu;  // the molecule itself lives in the middle row only
-				for (uint32_t j0 = jb; j0 < je; j0 += 4) {
+				uint32_t j0 = jb;
+				// full trips: four candidates, two per packed instruction, no range test
+				for (; j0 + 4u <= je; j0 += 4u) {
 					const uint32_t before = cnt;
-					// Only the last trip of a row can run past its end (up to 3 entries: the next cells of the region in
-					// linear order, which at partial bricks may be true neighbours listed again by their own row).
-					const uint32_t nvalid = je - j0;
-#pragma unroll
-					for (int u = 0; u < 4; ++u) {
-						const uint32_t j = j0 + u;
-						const double dx = xi - sx[j], dy = yi - sy[j], dz = zi - sz[j];
-						const double r2 = fma(dz, dz, fma(dy, dy, dx * dx));
-						const bool hit = (r2 < rcs2) & (j != self) & ((uint32_t)u < nvalid);
-						*reinterpret_cast<uint16_t*>(wb + (cnt & 7u) * (NT * 2)) = (uint16_t)(j * 8u);
-						cnt += hit ? 1u : 0u;
-					}
-					if ((cnt >> 2) != (before >> 2)) {  // a word of four entries is complete: flush it
-						const uint32_t w = before >> 2, s0 = (w & 1u) * 4u;
-						const uint64_t e0 = *reinterpret_cast<uint16_t*>(wb + (s0 + 0) * (NT * 2));
-						const uint64_t e1 = *reinterpret_cast<uint16_t*>(wb + (s0 + 1) * (NT * 2));
-						const uint64_t e2 = *reinterpret_cast<uint16_t*>(wb + (s0 + 2) * (NT * 2));
-						const uint64_t e3 = *reinterpret_cast<uint16_t*>(wb + (s0 + 3) * (NT * 2));
-						if (w < (uint32_t)VMAXW) wp[(size_t)w * 64] = e0 | (e1 << 16) | (e2 << 32) | (e3 << 48);
-					}
+					const f32x2 xa = *reinterpret_cast<const f32x2_a4*>(fx + j0), xb = *reinterpret_cast<const f32x2_a4*>(fx + j0 + 2);
+					const f32x2 ya = *reinterpret_cast<const f32x2_a4*>(fy + j0), yb = *reinterpret_cast<const f32x2_a4*>(fy + j0 + 2);
+					const f32x2 za = *reinterpret_cast<const f32x2_a4*>(fz + j0), zb = *reinterpret_cast<const f32x2_a4*>(fz + j0 + 2);
+					const f32x2 dxa = xi - xa, dya = yi - ya, dza = zi - za, dxb = xi - xb, dyb = yi - yb, dzb = zi - zb;
+					const f32x2 ra = __builtin_elementwise_fma(dza, dza, __builtin_elementwise_fma(dya, dya, dxa * dxa));
+					const f32x2 rb = __builtin_elementwise_fma(dzb, dzb, __builtin_elementwise_fma(dyb, dyb, dxb * dxb));
+					put(j0, (ra.x < thr) & (!SELF || j0 != ii));
+					put(j0 + 1u, (ra.y < thr) & (!SELF || j0 + 1u != ii));
+					put(j0 + 2u, (rb.x < thr) & (!SELF || j0 + 2u != ii));
+					put(j0 + 3u, (rb.y < thr) & (!SELF || j0 + 3u != ii));
+					flush(before);
 				}
-			}
+				// tail (up to 3 candidates): the entries past the row end are the next cells of the region in linear order,
+				// which at partial bricks may be true neighbours listed again by their own row — hence no overrun here
+				if (j0 < je) {
+					const uint32_t before = cnt;
+					for (uint32_t j = j0; j < je; ++j) {
+						const float dx = xi.x - fx[j], dy = yi.x - fy[j], dz = zi.x - fz[j];
+						const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+						put(j, (r2 < thr) & (!SELF || j != ii));
+					}
+					flush(before);
+				}
+			};
+			for (int row = 0; row < 4; ++row) scan_row(row, std::false_type());
+			scan_row(4, std::true_type());
+			for (int row = 5; row < 9; ++row) scan_row(row, std::false_type());
 			// the incomplete last word, padded with the dummy entry
 			const uint32_t w = cnt >> 2, rem = cnt & 3u;
 			if (rem && w < (uint32_t)VMAXW) {
-				const uint32_t s0 = (w & 1u) * 4u;
+				const char* const s0 = winb + ((w & 1u) * 4096u + wb);
 				uint64_t word = dummy;
 				for (uint32_t u = 0; u < rem; ++u) {
-					const uint64_t e = *reinterpret_cast<uint16_t*>(wb + (s0 + u) * (NT * 2));
+					const uint64_t e = *reinterpret_cast<const uint16_t*>(s0 + u * 1024u);
 					word = (word & ~(0xffffull << (16 * u))) | (e << (16 * u));
 				}
 				wp[(size_t)w * 64] = word;

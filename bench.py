@@ -150,6 +150,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line: libraries that print to file descriptor 1 (RCCL prints a version banner when the first
+    # communicator is created) are sent to stderr for the duration of the run; the result goes to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -182,7 +188,9 @@ def main():
         decomp = importlib.import_module("ls1-mardyn_amd.decomp")
         sim = decomp.build_strong_scaling_box(comps, RC, n, world, rank, local_rank, rho=RHO, temp=TEMP,
                                               cic=args.cic or None, kernel=args.kernel, stage_through_host=rehearse,
-                                              loopback=args.loopback)
+                                              loopback=args.loopback,
+                                              skin=(args.skin if args.skin > 0 and not args.no_fuse and args.kernel != 1
+                                                    and args.cic in (0, 1) else None))
         n_total = sim.n_global
         if args.loopback:  # rehearse the count exchange too (skipped otherwise when there is a single rank)
             sim.ex.force_count_exchange = True
@@ -221,7 +229,7 @@ def main():
 
     def run(k):
         if sim is not None:
-            return sim.run(DT, k, fuse=not args.no_fuse)
+            return sim.run(DT, k, fuse=not args.no_fuse, lists=None if os.environ.get("LS1_BENCH_DECOMP_LISTS", "1") != "0" else False)
         return eng.run(DT, k)
 
     def sync():
@@ -324,10 +332,12 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if world > 1 or args.decomp:
         import torch.distributed as dist
-        dist.destroy_process_group()
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

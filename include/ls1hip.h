@@ -237,6 +237,25 @@ int ls1hip_long_range_homogeneous(ls1hip_ctx* ctx, const uint64_t* n_per_compone
  * are evaluated from global memory: correct, slow — for tests).  Read-only options "verlet_lists", "verlet_builds", "verlet_steps". */
 int ls1hip_set_verlet(ls1hip_ctx* ctx, int enabled, double skin);
 
+/* The list mode piecewise — what a transport-driven multi-rank loop calls between two rebuilds (ls1hip_run is the
+ * single-rank loop built from the same pieces).  Between rebuilds no molecule changes its owner (it may sit up to
+ * skin / 2 outside its rank's box) and every halo copy keeps its slot; per step only POSITIONS travel:
+ *   rebuild step:  ls1hip_rebin -> leaving exchange -> ls1hip_halo -> halo exchange (kind 1) -> ls1hip_verlet_build
+ *                  -> ls1hip_forces_list
+ *   reuse step:    ls1hip_forces_list(which=1) [inner bricks, needs owned positions only] || ls1hip_halo_refresh ->
+ *                  refresh exchange (kind 2: LS1HIP_REFRESH_DOUBLES = 3 doubles per record, the records of the build-time
+ *                  halo exchange in the same order and number: no count exchange) -> ls1hip_forces_list(which=2)
+ * ls1hip_forces_list: dt > 0 fuses the pass with the integration (as ls1hip_forces_kick_drift), dt = 0 leaves F.
+ * ls1hip_verlet_poll: after a fused pass — has this rank's displacement bound exceeded skin / 2?  The ranks must agree on
+ * a rebuild (reduce the flags with a maximum).
+ * Replaces, for these steps: DomainDecompBase::exchangeMolecules + LinkedCells::update (no migration, no re-sort) and the
+ * HALO_COPIES message of NeighbourCommunicationScheme.cpp:115-136 by a position-only message. */
+#define LS1HIP_REFRESH_DOUBLES 3
+int ls1hip_verlet_build(ls1hip_ctx* ctx);
+int ls1hip_halo_refresh(ls1hip_ctx* ctx);
+int ls1hip_forces_list(ls1hip_ctx* ctx, int which, double dt, double* upot, double* virial);
+int ls1hip_verlet_poll(ls1hip_ctx* ctx, int* need_rebuild);
+
 /* nsteps full time steps entirely on the device (single rank, all directions local), no host round trip
  * inside: the loop body of Simulation::simulate (Simulation.cpp:979-1167) for an NVE run without plugins.
  * out6 (may be NULL) = {upot, virial, summv2, sumIw2, N, rotDOF} of the LAST step. */
@@ -258,7 +277,8 @@ int ls1hip_run_log(ls1hip_ctx* ctx, size_t cap_rows, double* rows, size_t* nrows
  * Replaces: CommunicationPartner::initSend / unpack (parallel/CommunicationPartner.cpp:139-227,266-389). */
 #define LS1HIP_LEAVING_DOUBLES 15
 #define LS1HIP_HALO_DOUBLES 9
-/* kind: 0 = leaving molecules (valid after ls1hip_rebin), 1 = halo copies (valid after ls1hip_halo).
+/* kind: 0 = leaving molecules (valid after ls1hip_rebin), 1 = halo copies (valid after ls1hip_halo), 2 = position refresh of
+ * the halo copies of the last list build (valid after ls1hip_halo_refresh; the counts are those of that build).
  * counts[27]: molecules packed per direction (0 for local / open directions). */
 int ls1hip_export_counts(ls1hip_ctx* ctx, int kind, uint64_t counts[27]);
 /* Copy the packed records of direction `dir` into the DEVICE buffer dev_buf (capacity in records). */

@@ -54,6 +54,10 @@ SYMBOLS = {
     "ls1hip_set_thermostat": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     "ls1hip_long_range_homogeneous": (C.c_int, [C.c_void_p, _u64p, C.c_double, _dp, _dp]),
     "ls1hip_set_verlet": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "ls1hip_verlet_build": (C.c_int, [C.c_void_p]),
+    "ls1hip_halo_refresh": (C.c_int, [C.c_void_p]),
+    "ls1hip_forces_list": (C.c_int, [C.c_void_p, C.c_int, C.c_double, _dp, _dp]),
+    "ls1hip_verlet_poll": (C.c_int, [C.c_void_p, _ip]),
     "ls1hip_run": (C.c_int, [C.c_void_p, C.c_double, C.c_ulong, _dp]),
     "ls1hip_run_log": (C.c_int, [C.c_void_p, C.c_size_t, _dp, C.POINTER(C.c_size_t)]),
     "ls1hip_export_counts": (C.c_int, [C.c_void_p, C.c_int, _u64p]),
@@ -70,6 +74,7 @@ SYMBOLS = {
 
 LEAVING_DOUBLES = 15
 HALO_DOUBLES = 9
+REFRESH_DOUBLES = 3
 FK_AUTO, FK_GENERIC, FK_LDS_LIST = 0, 1, 2
 REC_ICRVQD, REC_ICRV, REC_IRV = 0, 1, 2
 REC_BYTES = {REC_ICRVQD: 116, REC_ICRV: 60, REC_IRV: 56}

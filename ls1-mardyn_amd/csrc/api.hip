@@ -101,6 +101,8 @@ static void free_mol(ls1hip_ctx* c) {
 	dfree(h.x); dfree(h.y); dfree(h.z); dfree(h.q0); dfree(h.q1); dfree(h.q2); dfree(h.q3); dfree(h.id); dfree(h.cid);
 	dfree(h.key); dfree(h.rank); dfree(h.src); dfree(h.dir);
 	dfree(c->d_halo_src); dfree(c->d_halo_dir);
+	dfree(c->d_exp_halo_src); dfree(c->d_imp_slot); dfree(c->d_s2s); dfree(c->d_exp_refresh);
+	c->vl_ready = false;
 	dfree(c->alt_x); dfree(c->alt_y); dfree(c->alt_z);
 	dfree(c->d_vl_words); dfree(c->d_vl_nw);
 	c->vl_words_cap = c->vl_tiles_cap = 0;
@@ -523,7 +525,9 @@ static int alloc_mol(ls1hip_ctx* c, size_t n) {
 	c->exp_off_leave[27] = offL;
 	c->exp_off_halo[27] = offH;
 	if ((rc = dalloc(c, &c->d_exp_leave, (size_t)offL * LS1HIP_LEAVING_DOUBLES)) ||
-		(rc = dalloc(c, &c->d_exp_halo, (size_t)offH * LS1HIP_HALO_DOUBLES)))
+		(rc = dalloc(c, &c->d_exp_halo, (size_t)offH * LS1HIP_HALO_DOUBLES)) || (rc = dalloc(c, &c->d_exp_halo_src, (size_t)offH)) ||
+		(rc = dalloc(c, &c->d_exp_refresh, (size_t)offH * 3)) || (rc = dalloc(c, &c->d_imp_slot, cap_halo)) ||
+		(rc = dalloc(c, &c->d_s2s, cap_halo)))
 		return rc;
 	c->cap_real = cap_real;
 	c->cap_halo = cap_halo;
@@ -750,6 +754,10 @@ static HaloArgs halo_args(ls1hip_ctx* c) {
 	a.idk = c->d_idk;
 	a.hsrc = c->d_halo_src;
 	a.hdir = c->d_halo_dir;
+	a.exp_src = c->d_exp_halo_src;
+	a.imp_slot = c->d_imp_slot;
+	a.imp_at = c->halo_import_at;
+	a.s2s = c->d_s2s;
 	a.shell = c->d_shell;
 	a.nshell = c->n_shell;
 	a.cnt = c->d_cnt;
@@ -804,6 +812,9 @@ extern "C" int ls1hip_halo(ls1hip_ctx* c) {
 	hipStream_t hs = halo_stream(c);
 	if (c->inner_in_flight) HIPCHK(c, hipStreamWaitEvent(hs, c->ev_owned, 0));  // the re-binned owned molecules
 	TimedScope ts(c, c->t_halo, hs);
+	c->halo_import_at = 0;
+	c->vl_ready = false;
+	if (c->vl_on && c->cap_halo) HIPCHK(c, hipMemsetAsync(c->d_s2s, 0xff, c->cap_halo * sizeof(uint32_t), hs));
 	HaloArgs a = halo_args(c);
 	launch_halo_generate(a, hs);
 	if (!c->has_remote) {
@@ -1291,6 +1302,109 @@ static int verlet_poll_rebuild(ls1hip_ctx* c, bool* need) {
 	}
 }
 
+// ---- list mode, piecewise (multi-rank loops drive these; ls1hip_run is the single-rank loop) -------------------------------
+static bool can_verlet_piecewise(const ls1hip_ctx* c) { return c->vl_on && can_fuse(c) && c->g.hw == 1; }
+
+extern "C" int ls1hip_verlet_build(ls1hip_ctx* c) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, can_verlet_piecewise(c), "neighbour lists need ls1hip_set_verlet, the single-centre LJ fast path and one cell per cutoff");
+	REQUIRE(c, c->binned && c->halo_valid, "neighbour lists are built from binned molecules and a populated halo");
+	REQUIRE(c, !c->inner_in_flight && !c->fused_split, "a split force pass is in flight");
+	HIPCHK(c, hipSetDevice(c->device));
+	int rc = verlet_build(c);
+	if (rc) return rc;
+	// the export counts / import total of this halo exchange are what every refresh until the next build repeats
+	if ((rc = sync_counters(c))) return rc;
+	for (int d = 0; d < 27; ++d) c->vl_exp_counts[d] = c->h_cnt->exp_halo[d];
+	c->vl_imp_total = c->halo_import_at;
+	c->vl_ready = true;
+	c->vl_fresh = true;
+	c->vl_bound_pending = false;
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_halo_refresh(ls1hip_ctx* c) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, c->vl_ready, "no neighbour lists (ls1hip_verlet_build)");
+	HIPCHK(c, hipSetDevice(c->device));
+	hipStream_t hs = halo_stream(c);
+	if (c->inner_in_flight) HIPCHK(c, hipStreamWaitEvent(hs, c->ev_owned, 0));  // positions of the owned molecules
+	TimedScope ts(c, c->t_halo, hs);
+	c->halo_import_at = 0;
+	HaloArgs a = halo_args(c);
+	const MolSoA& m = c->mol[c->cur];
+	double *x = c->pos_x ? c->pos_x : m.x, *y = c->pos_x ? c->pos_y : m.y, *z = c->pos_x ? c->pos_z : m.z;
+	launch_halo_refresh(a, x, y, z, x, y, z, hs);
+	if (c->has_remote) {
+		launch_refresh_pack(a, x, y, z, c->d_exp_refresh, hs);
+	} else {
+		c->halo_valid = true;
+		if (c->inner_in_flight) HIPCHK(c, hipEventRecord(c->ev_halo, hs));
+	}
+	HIPCHK(c, hipGetLastError());
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_forces_list(ls1hip_ctx* c, int which, double dt, double* upot, double* virial) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, which >= 0 && which <= 2, "which must be 0, 1 or 2");
+	REQUIRE(c, c->vl_ready, "no neighbour lists (ls1hip_verlet_build)");
+	REQUIRE(c, which == 1 || c->halo_valid, "halo positions are not current (ls1hip_halo_refresh / import_done(2))");
+	REQUIRE(c, dt >= 0., "dt must be >= 0 (0: forces only, > 0: fused with kick + kick + drift)");
+	const bool fuse = dt > 0.;
+	REQUIRE(c, (fuse && which == 2) ? c->fused_split == 1 : c->fused_split == 0,
+			"fused list passes must be which=0, or which=1 followed by which=2");
+	HIPCHK(c, hipSetDevice(c->device));
+	{
+		int rc = before_force_pass(c, which);
+		if (rc) return rc;
+		TimedScope ts(c, c->t_force);
+		ForcePass fp;
+		fp.which = which;
+		fp.fuse = fuse;
+		fp.dt = dt;
+		fp.vl = 2;
+		fp.lists_rebuilt = c->vl_fresh;
+		if ((rc = launch_forces(c, fp))) return rc;
+	}
+	if (which == 1) {
+		c->inner_in_flight = !c->halo_valid;
+		if (fuse) c->fused_split = 1;
+	} else if (fuse) {
+		// velocities are at t + dt/2 of the next step; the advanced positions wait in the other position buffer
+		const bool in_alt = c->pos_x == c->alt_x;
+		c->pos_x = in_alt ? nullptr : c->alt_x;
+		c->pos_y = in_alt ? nullptr : c->alt_y;
+		c->pos_z = in_alt ? nullptr : c->alt_z;
+		c->fused_split = 0;
+		c->vl_fresh = false;
+		c->vl_valid = true;
+		c->vl_bound_pending = true;
+		c->halo_valid = false;
+		c->forces_valid = false;
+		c->vl_steps++;
+	} else {
+		c->forces_valid = true;
+		c->vl_steps++;
+	}
+	if (upot || virial) {
+		int rc = sync_counters(c);
+		if (rc) return rc;
+		macro_to_upot_virial(c->h_cnt, upot, virial);
+	}
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_verlet_poll(ls1hip_ctx* c, int* need_rebuild) {
+	if (!c || !need_rebuild) return LS1HIP_EINVAL;
+	REQUIRE(c, c->vl_bound_pending, "no fused list pass has published a displacement bound");
+	bool need = true;
+	int rc = verlet_poll_rebuild(c, &need);
+	if (rc) return rc;
+	*need_rebuild = need ? 1 : 0;
+	return LS1HIP_OK;
+}
+
 extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double* out6) {
 	if (!c) return LS1HIP_EINVAL;
 	REQUIRE(c, !c->has_remote, "ls1hip_run drives single-rank domains only (use the piecewise calls with a transport)");
@@ -1569,8 +1683,13 @@ extern "C" int ls1hip_download_forces(ls1hip_ctx* c, size_t cap, double* F, doub
 // ---- multi-GPU plumbing --------------------------------------------------------------------------------------------
 extern "C" int ls1hip_export_counts(ls1hip_ctx* c, int kind, uint64_t counts[27]) {
 	if (!c || !counts) return LS1HIP_EINVAL;
-	REQUIRE(c, kind == 0 || kind == 1, "kind must be 0 or 1");
+	REQUIRE(c, kind >= 0 && kind <= 2, "kind must be 0, 1 or 2");
 	HIPCHK(c, hipSetDevice(c->device));
+	if (kind == 2) {  // position refresh of the halo copies exported when the lists were built: the counts are frozen
+		REQUIRE(c, c->vl_ready, "no neighbour lists (ls1hip_verlet_build)");
+		for (int d = 0; d < 27; ++d) counts[d] = c->vl_exp_counts[d];
+		return LS1HIP_OK;
+	}
 	int rc = sync_counters(c, kind == 1 ? halo_stream(c) : c->stream);
 	if (rc) return rc;
 	for (int d = 0; d < 27; ++d) counts[d] = kind == 0 ? c->h_cnt->exp_leave[d] : c->h_cnt->exp_halo[d];
@@ -1578,11 +1697,11 @@ extern "C" int ls1hip_export_counts(ls1hip_ctx* c, int kind, uint64_t counts[27]
 }
 
 static int export_pack_async(ls1hip_ctx* c, int kind, int dir, double* dst, size_t cap, uint32_t* n_out, hipStream_t st) {
-	const uint32_t n = kind == 0 ? c->h_cnt->exp_leave[dir] : c->h_cnt->exp_halo[dir];
+	const uint32_t n = kind == 0 ? c->h_cnt->exp_leave[dir] : (kind == 1 ? c->h_cnt->exp_halo[dir] : c->vl_exp_counts[dir]);
 	REQUIRE(c, cap >= n, "export buffer too small: %zu < %u records", cap, n);
-	const int w = kind == 0 ? LS1HIP_LEAVING_DOUBLES : LS1HIP_HALO_DOUBLES;
+	const int w = kind == 0 ? LS1HIP_LEAVING_DOUBLES : (kind == 1 ? LS1HIP_HALO_DOUBLES : LS1HIP_REFRESH_DOUBLES);
 	const double* src = kind == 0 ? c->d_exp_leave + (size_t)c->exp_off_leave[dir] * w
-								  : c->d_exp_halo + (size_t)c->exp_off_halo[dir] * w;
+								  : (kind == 1 ? c->d_exp_halo : c->d_exp_refresh) + (size_t)c->exp_off_halo[dir] * w;
 	launch_pack_copy(dst, src, n * w, st);
 	*n_out = n;
 	return LS1HIP_OK;
@@ -1590,10 +1709,11 @@ static int export_pack_async(ls1hip_ctx* c, int kind, int dir, double* dst, size
 
 extern "C" int ls1hip_export_pack(ls1hip_ctx* c, int kind, int dir, void* dev_buf, size_t cap) {
 	if (!c) return LS1HIP_EINVAL;
-	REQUIRE(c, (kind == 0 || kind == 1) && dir >= 0 && dir < 27 && dev_buf, "bad argument");
+	REQUIRE(c, kind >= 0 && kind <= 2 && dir >= 0 && dir < 27 && dev_buf, "bad argument");
+	REQUIRE(c, kind != 2 || c->vl_ready, "no neighbour lists (ls1hip_verlet_build)");
 	HIPCHK(c, hipSetDevice(c->device));
 	uint32_t n = 0;
-	hipStream_t st = kind == 1 ? halo_stream(c) : c->stream;
+	hipStream_t st = kind != 0 ? halo_stream(c) : c->stream;
 	int rc = export_pack_async(c, kind, dir, (double*)dev_buf, cap, &n, st);
 	if (rc) return rc;
 	HIPCHK(c, hipStreamSynchronize(st));  // the transport runs on its own stream
@@ -1602,16 +1722,16 @@ extern "C" int ls1hip_export_pack(ls1hip_ctx* c, int kind, int dir, void* dev_bu
 
 extern "C" int ls1hip_export_pack_dirs(ls1hip_ctx* c, int kind, const int* dirs, int ndirs, void* dev_buf, size_t cap) {
 	if (!c) return LS1HIP_EINVAL;
-	REQUIRE(c, (kind == 0 || kind == 1) && ndirs >= 0 && ndirs <= 27 && (ndirs == 0 || dirs) && (cap == 0 || dev_buf),
-			"bad argument");
+	REQUIRE(c, kind >= 0 && kind <= 2 && ndirs >= 0 && ndirs <= 27 && (ndirs == 0 || dirs) && (cap == 0 || dev_buf), "bad argument");
+	REQUIRE(c, kind != 2 || c->vl_ready, "no neighbour lists (ls1hip_verlet_build)");
 	HIPCHK(c, hipSetDevice(c->device));
-	const int w = kind == 0 ? LS1HIP_LEAVING_DOUBLES : LS1HIP_HALO_DOUBLES;
+	const int w = kind == 0 ? LS1HIP_LEAVING_DOUBLES : (kind == 1 ? LS1HIP_HALO_DOUBLES : LS1HIP_REFRESH_DOUBLES);
 	PackSegments seg;
 	seg.n = 0;
 	size_t used = 0;
 	for (int k = 0; k < ndirs; ++k) {
 		REQUIRE(c, dirs[k] >= 0 && dirs[k] < 27, "direction %d out of range", dirs[k]);
-		const uint32_t n = kind == 0 ? c->h_cnt->exp_leave[dirs[k]] : c->h_cnt->exp_halo[dirs[k]];
+		const uint32_t n = kind == 0 ? c->h_cnt->exp_leave[dirs[k]] : (kind == 1 ? c->h_cnt->exp_halo[dirs[k]] : c->vl_exp_counts[dirs[k]]);
 		REQUIRE(c, cap - used >= n, "export buffer too small: %zu < %zu records", cap, used + n);
 		if (n == 0) continue;
 		seg.src_off[seg.n] = (uint64_t)(kind == 0 ? c->exp_off_leave[dirs[k]] : c->exp_off_halo[dirs[k]]) * w;
@@ -1620,8 +1740,8 @@ extern "C" int ls1hip_export_pack_dirs(ls1hip_ctx* c, int kind, const int* dirs,
 		used += n;
 	}
 	seg.total = (uint64_t)used * w;
-	hipStream_t st = kind == 1 ? halo_stream(c) : c->stream;
-	launch_pack_segments(seg, kind == 0 ? c->d_exp_leave : c->d_exp_halo, (double*)dev_buf, st);
+	hipStream_t st = kind != 0 ? halo_stream(c) : c->stream;
+	launch_pack_segments(seg, kind == 0 ? c->d_exp_leave : (kind == 1 ? c->d_exp_halo : c->d_exp_refresh), (double*)dev_buf, st);
 	HIPCHK(c, hipGetLastError());
 	HIPCHK(c, hipStreamSynchronize(st));  // one synchronisation per message set: the transport runs on its own stream
 	return LS1HIP_OK;
@@ -1629,9 +1749,19 @@ extern "C" int ls1hip_export_pack_dirs(ls1hip_ctx* c, int kind, const int* dirs,
 
 extern "C" int ls1hip_import(ls1hip_ctx* c, int kind, const void* dev_buf, size_t n) {
 	if (!c) return LS1HIP_EINVAL;
-	REQUIRE(c, kind == 0 || kind == 1, "kind must be 0 or 1");
+	REQUIRE(c, kind >= 0 && kind <= 2, "kind must be 0, 1 or 2");
 	REQUIRE(c, n == 0 || dev_buf, "null buffer");
 	HIPCHK(c, hipSetDevice(c->device));
+	if (kind == 2) {
+		REQUIRE(c, c->vl_ready, "no neighbour lists (ls1hip_verlet_build)");
+		REQUIRE(c, c->halo_import_at + n <= c->vl_imp_total, "more refresh records than halo records were imported at build time");
+		HaloArgs a = halo_args(c);
+		const MolSoA& m = c->mol[c->cur];
+		launch_refresh_import(a, (const double*)dev_buf, (uint32_t)n, c->pos_x ? c->pos_x : m.x, c->pos_x ? c->pos_y : m.y,
+							  c->pos_x ? c->pos_z : m.z, halo_stream(c));
+		c->halo_import_at += (uint32_t)n;
+		return LS1HIP_OK;
+	}
 	if (kind == 0) {
 		REQUIRE(c, c->pending_in + n <= c->cap_real, "owned-molecule capacity exceeded by immigration");
 		RebinArgs a = rebin_args(c, c->pending_in);
@@ -1640,6 +1770,7 @@ extern "C" int ls1hip_import(ls1hip_ctx* c, int kind, const void* dev_buf, size_
 	} else {
 		HaloArgs a = halo_args(c);
 		launch_halo_import(a, (const double*)dev_buf, (uint32_t)n, halo_stream(c));
+		c->halo_import_at += (uint32_t)n;
 	}
 	// asynchronous: dev_buf is read on the engine's stream and must stay valid until ls1hip_import_done(kind) returns
 	return LS1HIP_OK;
@@ -1647,9 +1778,19 @@ extern "C" int ls1hip_import(ls1hip_ctx* c, int kind, const void* dev_buf, size_
 
 extern "C" int ls1hip_import_done(ls1hip_ctx* c, int kind) {
 	if (!c) return LS1HIP_EINVAL;
-	REQUIRE(c, kind == 0 || kind == 1, "kind must be 0 or 1");
+	REQUIRE(c, kind >= 0 && kind <= 2, "kind must be 0, 1 or 2");
 	HIPCHK(c, hipSetDevice(c->device));
 	if (!c->has_remote) return LS1HIP_OK;  // purely local domain: ls1hip_rebin / ls1hip_halo already finished the phase
+	if (kind == 2) {
+		REQUIRE(c, c->vl_ready, "no neighbour lists (ls1hip_verlet_build)");
+		REQUIRE(c, c->halo_import_at == c->vl_imp_total, "%u refresh records imported, %u halo records were imported at build time",
+				c->halo_import_at, c->vl_imp_total);
+		hipStream_t hs = halo_stream(c);
+		c->halo_valid = true;
+		if (c->inner_in_flight) HIPCHK(c, hipEventRecord(c->ev_halo, hs));
+		HIPCHK(c, hipStreamSynchronize(hs));  // imported buffers may be released by the caller from here on
+		return LS1HIP_OK;
+	}
 	if (kind == 0) {
 		REQUIRE(c, !c->binned, "import_done(0) without a pending ls1hip_rebin");
 		int rc = do_rebin_finish(c, c->pending_in);

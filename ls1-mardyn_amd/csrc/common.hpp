@@ -183,6 +183,14 @@ struct ls1hip_ctx {
 	bool vl_valid = false;       // the lists match the current binning and the displacement bound is tracked on the device
 	uint32_t *d_halo_src = nullptr;
 	uint8_t* d_halo_dir = nullptr;
+	uint32_t *d_exp_halo_src = nullptr, *d_imp_slot = nullptr, *d_s2s = nullptr;
+	double* d_exp_refresh = nullptr;  // 3 doubles per export slot
+	uint32_t vl_exp_counts[27] = {0};  // halo export counts of the exchange the lists were built from
+	uint32_t vl_imp_total = 0;         // halo records imported in that exchange
+	uint32_t halo_import_at = 0;      // halo records imported since the last ls1hip_halo (build) / ls1hip_halo_refresh
+	bool vl_ready = false;            // lists built for the current binning (piecewise / multi-rank list mode)
+	bool vl_fresh = false;            // no fused list pass since the build: the displacement bound restarts with the next one
+	bool vl_bound_pending = false;    // a fused list pass has published a rebuild flag that was not read yet
 	volatile uint32_t* h_flag = nullptr;  // host-visible {seq << 1 | rebuild needed}, written by the step's last reduction
 	uint32_t* d_flag = nullptr;
 	uint32_t vl_seq = 0;
@@ -226,6 +234,11 @@ struct HaloArgs {
 	HaloStage hs;
 	uint32_t* hsrc;  // per sorted halo copy: owned index of its source molecule / direction of its shift (list-reuse
 	uint8_t* hdir;   // mode refreshes the halo positions from these instead of regenerating the images)
+	// multi-rank list-reuse: what a refresh needs to route positions without re-sorting
+	uint32_t* exp_src;   // per export slot (layout of exp_halo): owned index of the exported molecule
+	uint32_t* imp_slot;  // per received record (arrival order over the imports of this exchange): its staging slot
+	uint32_t imp_at;     // records received before this import call
+	uint32_t* s2s;       // per staging slot: index of the copy inside the sorted halo segment
 	bool has_rot;
 	uint32_t *perm, *count, *cell_begin, *cell_end, *blocksum;
 	uint64_t* idk;  // ids of the staged halo copies in slot order (canonical in-cell order by counting, as in k_gather)
@@ -247,6 +260,10 @@ void launch_halo_finalize(const HaloArgs& a, hipStream_t s);
 // positions of the halo copies recomputed from their source molecules: dst[n_real + k] = src[hsrc[k]] + shift[hdir[k]]
 void launch_halo_refresh(const HaloArgs& a, const double* sx, const double* sy, const double* sz, double* dx, double* dy,
 						 double* dz, hipStream_t s);
+// positions (receiver frame) of the molecules exported as halo copies at build time -> out[slot * 3 ..], export slot layout
+void launch_refresh_pack(const HaloArgs& a, const double* sx, const double* sy, const double* sz, double* out, hipStream_t s);
+// received refresh records (3 doubles each, build-time arrival order) -> halo segment of the position buffer dx / dy / dz
+void launch_refresh_import(const HaloArgs& a, const double* rec, uint32_t n, double* dx, double* dy, double* dz, hipStream_t s);
 void launch_leave_import(const RebinArgs& a, const double* dev_records, uint32_t n, uint32_t at, hipStream_t s);
 void launch_pack_copy(double* dst, const double* src, uint32_t ndoubles, hipStream_t s);
 // up to 27 (source offset -> destination offset) runs of doubles copied by one launch; dst_off is ascending

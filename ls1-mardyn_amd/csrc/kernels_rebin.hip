@@ -475,6 +475,7 @@ __device__ __forceinline__ void halo_emit(const HaloArgs& a, uint32_t p, const d
 			return;
 		}
 		double* rec = a.exp_halo + (size_t)(a.exp_off[dir] + slot) * LS1HIP_HALO_DOUBLES;
+		a.exp_src[a.exp_off[dir] + slot] = p;  // list-reuse mode re-sends only the position of this molecule
 		rec[0] = __longlong_as_double((long long)id);
 		rec[1] = __longlong_as_double((long long)cid);
 		rec[2] = rn[0];
@@ -573,6 +574,7 @@ __global__ void __launch_bounds__(HI_TPB) k_halo_import(HaloArgs a, const double
 		return;
 	}
 	const double rr[3] = {r[2], r[3], r[4]};
+	a.imp_slot[a.imp_at + i] = slot;
 	halo_stage_write(a, slot, rr, (uint64_t)__double_as_longlong(r[0]), (int32_t)__double_as_longlong(r[1]), r[5], r[6],
 					 r[7], r[8], 0xffffffffu, 13);
 }
@@ -593,6 +595,7 @@ __global__ void __launch_bounds__(TPB) k_halo_gather(HaloArgs a) {
 	}
 	a.hsrc[p - n_real] = a.hs.src[i];
 	a.hdir[p - n_real] = a.hs.dir[i];
+	a.s2s[i] = p - n_real;
 	a.mol.x[p] = a.hs.x[i];
 	a.mol.y[p] = a.hs.y[i];
 	a.mol.z[p] = a.hs.z[i];
@@ -660,6 +663,39 @@ void launch_halo_refresh(const HaloArgs& a, const double* sx, const double* sy, 
 						 double* dz, hipStream_t s) {
 	if (a.cap_halo == 0) return;
 	hipLaunchKernelGGL(k_halo_refresh, dim3((a.cap_halo + TPB - 1) / TPB), dim3(TPB), 0, s, a, sx, sy, sz, dx, dy, dz);
+}
+
+// Multi-rank list-reuse: the molecules exported as halo copies at build time re-send only their current position
+// (receiver frame), in the build-time slot layout; the receiver routes record j of the (identically ordered) message to
+// the slot its build-time twin was sorted into.
+__global__ void __launch_bounds__(TPB) k_refresh_pack(HaloArgs a, const double* sx, const double* sy, const double* sz, double* out) {
+	const uint32_t g = blockIdx.x * TPB + threadIdx.x;
+	if (g >= a.exp_off[27]) return;
+	int dir = 0;
+	while (dir < 26 && g >= a.exp_off[dir + 1]) ++dir;
+	if (g - a.exp_off[dir] >= a.cnt->exp_halo[dir]) return;
+	const uint32_t p = a.exp_src[g];
+	out[(size_t)g * 3] = sx[p] + a.shift[dir][0];
+	out[(size_t)g * 3 + 1] = sy[p] + a.shift[dir][1];
+	out[(size_t)g * 3 + 2] = sz[p] + a.shift[dir][2];
+}
+void launch_refresh_pack(const HaloArgs& a, const double* sx, const double* sy, const double* sz, double* out, hipStream_t s) {
+	if (a.exp_off[27] == 0) return;
+	hipLaunchKernelGGL(k_refresh_pack, dim3((a.exp_off[27] + TPB - 1) / TPB), dim3(TPB), 0, s, a, sx, sy, sz, out);
+}
+__global__ void __launch_bounds__(TPB) k_refresh_import(HaloArgs a, const double* rec, uint32_t n, double* dx, double* dy, double* dz) {
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t k = a.s2s[a.imp_slot[a.imp_at + i]];
+	if (k == 0xffffffffu) return;  // its build-time twin was rejected (error already flagged)
+	const uint32_t p = a.cnt->n_real + k;
+	dx[p] = rec[(size_t)i * 3];
+	dy[p] = rec[(size_t)i * 3 + 1];
+	dz[p] = rec[(size_t)i * 3 + 2];
+}
+void launch_refresh_import(const HaloArgs& a, const double* rec, uint32_t n, double* dx, double* dy, double* dz, hipStream_t s) {
+	if (n == 0) return;
+	hipLaunchKernelGGL(k_refresh_import, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, s, a, rec, n, dx, dy, dz);
 }
 
 void launch_halo_finalize(const HaloArgs& a, hipStream_t s) {

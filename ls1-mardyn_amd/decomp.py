@@ -23,8 +23,8 @@ import os
 
 import numpy as np
 
-LEAVING, HALO = 0, 1
-RECORD_DOUBLES = {LEAVING: 15, HALO: 9}
+LEAVING, HALO, REFRESH = 0, 1, 2
+RECORD_DOUBLES = {LEAVING: 15, HALO: 9, REFRESH: 3}
 
 
 class DecompositionError(RuntimeError):
@@ -195,8 +195,6 @@ class HaloExchanger:
     def exchange(self, kind: int, overlap_fn=None):
         """Counts -> all_gather; payload -> one message per peer.  `overlap_fn` (optional) is called after the sends
         and receives have been posted and before they are waited for (inner-cell force launch goes here)."""
-        torch, dist = self._torch, self.dist
-        w = RECORD_DOUBLES[kind]
         # Error handling is COLLECTIVE: the count table carries a status column.  An engine error on this rank (export /
         # halo capacity overflow, a molecule beyond the halo region — raised by export_counts / import_done) is not thrown
         # here but gathered, and every rank raises after the all_gather, before any point-to-point operation is posted.
@@ -206,6 +204,7 @@ class HaloExchanger:
             self._deferred = self._deferred or e
             counts = np.zeros(27, dtype=np.int64)
         status = np.int64(1 if self._deferred is not None else 0)
+        allc = counts[None, :]
         if self.peers:
             table = self._gather_counts(np.concatenate([counts, [status]]))
             allc, stat = table[:, :27], table[:, 27]
@@ -215,6 +214,20 @@ class HaloExchanger:
                 raise DecompositionError(f"rank(s) {bad} reported an engine error during the exchange of kind {kind}{mine}")
         elif self._deferred is not None:
             raise self._deferred
+        if kind == HALO:
+            self._halo_counts = (counts.copy(), np.array(allc, copy=True))  # what every position refresh until the next build repeats
+        self._transfer(kind, counts, allc, overlap_fn)
+
+    def exchange_refresh(self, overlap_fn=None):
+        """List-reuse step: the halo copies of the last list build get their current positions.  Same messages as that
+        build's halo exchange (same peers, directions, record order and counts) with 3 doubles per record — no count
+        exchange, no host synchronisation on counters."""
+        counts, allc = self._halo_counts
+        self._transfer(REFRESH, counts, allc, overlap_fn)
+
+    def _transfer(self, kind, counts, allc, overlap_fn=None):
+        torch, dist = self._torch, self.dist
+        w = RECORD_DOUBLES[kind]
         # ONE device buffer holds every outgoing message (directions grouped by peer) and ONE every incoming message:
         # one pack call / one import call / one stream synchronisation per exchange, whatever the number of peers
         n_out = {p: int(sum(counts[d] for d in self._outgoing[p])) for p in self.peers}
@@ -331,13 +344,15 @@ class DistributedSimulation:
         kin = e.kick(0.5 * dt, want_sums=want)
         return macro, kin
 
-    def run(self, dt, nsteps, fuse=True):
+    def run(self, dt, nsteps, fuse=True, lists=None):
         """nsteps full time steps.  Between two steps the post-force kick and the next pre-force kick + drift are
         either done by the force pass itself (fused / reduced-memory mode, when the engine offers it) or by one pass
         over the molecules (ls1hip_kick_then_kick_drift); both are bitwise the same as the separate calls.  The last
         step is unfused: forces and kinetic sums are needed for the global values."""
         e = self.engine
         fuse = bool(fuse) and getattr(e, "can_fuse_integration", lambda: False)()
+        if fuse and lists is not False and getattr(e, "can_verlet", lambda: False)():
+            return self.run_lists(dt, nsteps)
         out = None
         advanced = False
         for s in range(nsteps):
@@ -350,6 +365,50 @@ class DistributedSimulation:
                 e.kick_then_kick_drift(dt)
             advanced = fuse and not last
             macro = self._exchange_and_forces(last, dt if advanced else None)
+            if last:
+                kin = e.kick(0.5 * dt, want_sums=True)
+                out = self.reduce_globals(macro, kin)
+        return out
+
+    def _collective_rebuild(self):
+        """Has ANY rank's displacement bound exceeded skin / 2?  (A rebuild moves molecules between ranks: all or none.)"""
+        torch = self._torch
+        need = 1.0 if self.engine.verlet_poll() else 0.0
+        if self.dc.world == 1:
+            return need > 0
+        t = torch.tensor([need], dtype=torch.float64, device="cpu" if (self.stage or self.device.type != "cuda") else self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return float(t.item()) > 0
+
+    def run_lists(self, dt, nsteps):
+        """The decomposed loop in list mode (ls1hip_set_verlet): between two rebuilds no migration, no re-binning, no halo
+        regeneration and no count exchange — the halo copies receive their current positions through the messages of the
+        build-time halo exchange (3 doubles per record), overlapped with the inner-brick pass.  Rebuild steps (all ranks
+        together, when any rank's displacement bound exceeds skin / 2) run the full exchange and rebuild the lists."""
+        e = self.engine
+        out = None
+        advanced = False
+        for s in range(nsteps):
+            last = s == nsteps - 1
+            if advanced:
+                rebuild = self._collective_rebuild()
+            else:
+                e.kick_drift(dt)  # only the first step of a run integrates separately
+                rebuild = True
+            advanced = not last
+            fdt = dt if advanced else 0.0
+            if rebuild:
+                e.rebin()
+                self.ex.exchange(LEAVING)
+                e.halo()
+                self.ex.exchange(HALO)
+                e.verlet_build()
+                macro = e.forces_list(0, fdt, want_macro=last)
+            else:
+                e.forces_list(1, fdt)        # inner bricks: owned positions only
+                e.halo_refresh()             # second stream: local images + packing for the peers
+                self.ex.exchange_refresh()   # ... while the inner pass computes
+                macro = e.forces_list(2, fdt, want_macro=last)
             if last:
                 kin = e.kick(0.5 * dt, want_sums=True)
                 out = self.reduce_globals(macro, kin)
@@ -372,7 +431,7 @@ class DistributedSimulation:
 
 
 def build_strong_scaling_box(comps, rc, n_per_dim, world, rank, local_rank, rho, temp, cic=None, kernel=0,
-                             stage_through_host=False, loopback=False, options=None):
+                             stage_through_host=False, loopback=False, options=None, skin=None):
     """bench.py helper: the GLOBAL jittered bcc liquid of 2*n^3 molecules (synth.py) split over the rank grid; every
     rank generates exactly the molecules of its own sub-box, in device memory, chunk by chunk."""
     import torch
@@ -393,6 +452,8 @@ def build_strong_scaling_box(comps, rc, n_per_dim, world, rank, local_rank, rho,
     eng.set_option("force_kernel", kernel)
     for k, v in (options or {}).items():
         eng.set_option(k, v)
+    if skin:
+        eng.set_verlet(skin)
     eng.set_domain(global_len, lo, hi, rank, dc.neighbor_table())
     dev = torch.device("cuda", local_rank)
     # upper bound of the sub-box population (uniform density + the jitter band on every face)

@@ -226,6 +226,29 @@ class DeviceEngine:
         on = bool(skin) and skin > 0
         self._chk(self.lib.ls1hip_set_verlet(self.ctx, (2 if force else 1) if on else 0, float(skin) if on else 0.0))
 
+    # list mode, piecewise (multi-rank loops; see ls1hip.h)
+    def can_verlet(self) -> bool:
+        return bool(self.get_option("verlet_lists")) and self.can_fuse_integration()
+
+    def verlet_build(self):
+        self._chk(self.lib.ls1hip_verlet_build(self.ctx))
+
+    def halo_refresh(self):
+        self._chk(self.lib.ls1hip_halo_refresh(self.ctx))
+
+    def forces_list(self, which: int, dt: float = 0.0, want_macro: bool = False):
+        if not want_macro:
+            self._chk(self.lib.ls1hip_forces_list(self.ctx, int(which), float(dt), None, None))
+            return None
+        u = C.c_double(); w = C.c_double()
+        self._chk(self.lib.ls1hip_forces_list(self.ctx, int(which), float(dt), C.byref(u), C.byref(w)))
+        return u.value, w.value
+
+    def verlet_poll(self) -> bool:
+        n = C.c_int()
+        self._chk(self.lib.ls1hip_verlet_poll(self.ctx, C.byref(n)))
+        return bool(n.value)
+
     def long_range_homogeneous(self, n_per_component, global_rho):
         n = np.ascontiguousarray(n_per_component, dtype=np.uint64)
         u = C.c_double(); w = C.c_double()

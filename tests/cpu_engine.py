@@ -11,10 +11,12 @@ import numpy as np
 
 
 class CpuEngine:
-    def __init__(self, global_len, bmin, bmax, my_rank, nbr, rc, eps24=24.0, sig2=1.0, mass=1.0):
+    def __init__(self, global_len, bmin, bmax, my_rank, nbr, rc, eps24=24.0, sig2=1.0, mass=1.0, skin=None):
         self.L = np.asarray(global_len, float); self.bmin = np.asarray(bmin, float); self.bmax = np.asarray(bmax, float)
         self.rank = my_rank; self.nbr = np.asarray(nbr); self.rc = rc
         self.eps24, self.sig2, self.mass = eps24, sig2, mass
+        self.skin = skin  # list mode (ls1hip_set_verlet): halo shell of rc + skin, refreshable halo copies
+        self.rc_halo = rc + (skin or 0.0)
         self.shift = np.zeros((27, 3))
         for sz in (-1, 0, 1):
             for sy in (-1, 0, 1):
@@ -25,7 +27,7 @@ class CpuEngine:
                             self.shift[d, k] = self.L[k]
                         if s > 0 and self.bmax[k] == self.L[k]:
                             self.shift[d, k] = -self.L[k]
-        self.exp = {0: [np.zeros((0, 15))] * 27, 1: [np.zeros((0, 9))] * 27}
+        self.exp = {0: [np.zeros((0, 15))] * 27, 1: [np.zeros((0, 9))] * 27, 2: [np.zeros((0, 3))] * 27}
         self.pending = []
         self.halo_r = np.zeros((0, 3))
         self.F = None
@@ -72,8 +74,10 @@ class CpuEngine:
     def halo(self):
         out = [[] for _ in range(27)]
         self.pending = []
-        lo = self.r < self.bmin + self.rc
-        hi = self.r >= self.bmax - self.rc
+        self.pending_src = []  # per pending block: (owned indices, shift) of a local image block, None for imported records
+        self.exp_src = [np.zeros(0, int)] * 27
+        lo = self.r < self.bmin + self.rc_halo
+        hi = self.r >= self.bmax - self.rc_halo
         for sz in (-1, 0, 1):
             for sy in (-1, 0, 1):
                 for sx in (-1, 0, 1):
@@ -89,7 +93,9 @@ class CpuEngine:
                     rr = self.r[m] + self.shift[d]
                     if dest == self.rank:
                         self.pending.append(rr)
+                        self.pending_src.append((np.nonzero(m)[0], self.shift[d].copy()))
                     else:
+                        self.exp_src[d] = np.nonzero(m)[0]
                         rec = np.zeros((len(rr), 9))
                         rec[:, 0] = self.ids[m].view(np.float64); rec[:, 2:5] = rr; rec[:, 5] = 1.0
                         out[d] = rec
@@ -108,7 +114,7 @@ class CpuEngine:
         self._view(ptr, rec.size)[:] = rec.reshape(-1)
 
     def export_pack_dirs(self, kind, dirs, ptr, cap):
-        w = 15 if kind == 0 else 9
+        w = {0: 15, 1: 9, 2: 3}[kind]
         off = 0
         for d in dirs:
             rec = self.exp[kind][d]
@@ -117,15 +123,29 @@ class CpuEngine:
             off += len(rec)
 
     def import_records(self, kind, ptr, n):
-        w = 15 if kind == 0 else 9
+        w = {0: 15, 1: 9, 2: 3}[kind]
         rec = self._view(ptr, n * w).reshape(n, w).copy()
+        if kind == 2:  # position refresh: the records of the build-time halo imports, same order
+            for k, src in enumerate(self.pending_src):
+                if src is None and self._refresh_cursor[k] is not None and len(rec):
+                    m = len(self.pending[k])
+                    if self._refresh_cursor[k] == 0:
+                        self.pending[k] = rec[:m].copy()
+                        rec = rec[m:]
+                        self._refresh_cursor[k] = None
+            assert len(rec) == 0
+            return
         if kind == 0:
             self.ids = np.concatenate([self.ids, rec[:, 0].copy().view(np.uint64)])
             self.r = np.concatenate([self.r, rec[:, 2:5]]); self.v = np.concatenate([self.v, rec[:, 5:8]])
         else:
             self.pending.append(rec[:, 2:5])
+            self.pending_src.append(None)
 
     def import_done(self, kind):
+        if kind == 2:
+            self.halo_r = np.concatenate(self.pending) if self.pending else np.zeros((0, 3))
+            return
         if kind == 0:
             assert np.all(self.r >= self.bmin) and np.all(self.r < self.bmax)
             self.F = np.zeros_like(self.r)
@@ -171,3 +191,29 @@ class CpuEngine:
     def kick(self, dt_half, want_sums=True):
         self.v += dt_half / self.mass * self.F
         return (float(self.mass * (self.v ** 2).sum()), 0.0, len(self.v), 0) if want_sums else None
+
+    # --- list mode (ls1hip_verlet_build / ls1hip_halo_refresh / ls1hip_forces_list / ls1hip_verlet_poll)
+    def can_verlet(self):
+        return self.skin is not None
+
+    def verlet_build(self):
+        self.r0 = self.r.copy()  # (the stand-in keeps no lists: brute force over owned + halo copies)
+
+    def halo_refresh(self):
+        for k, src in enumerate(self.pending_src):
+            if src is not None:
+                self.pending[k] = self.r[src[0]] + src[1]
+        self._refresh_cursor = [0 if src is None else None for src in self.pending_src]
+        self.exp[2] = [self.r[self.exp_src[d]] + self.shift[d] if len(self.exp_src[d]) else np.zeros((0, 3)) for d in range(27)]
+        if not any(src is None for src in self.pending_src):
+            self.halo_r = np.concatenate(self.pending) if self.pending else np.zeros((0, 3))
+
+    def forces_list(self, which, dt=0.0, want_macro=False):
+        out = self.forces(which, want_macro)
+        if which != 1 and dt > 0:
+            self.v += dt / self.mass * self.F
+            self.r += dt * self.v
+        return out
+
+    def verlet_poll(self):
+        return bool(np.sqrt(((self.r - self.r0) ** 2).sum(1)).max() > 0.5 * self.skin) if len(self.r) else False

@@ -25,7 +25,8 @@ def main():
     dc = decomp.CartesianDecomposition(world, rank, L, grid, loopback=bool(int(os.environ.get("LS1_TEST_LOOPBACK", "0"))))
     lo, hi = dc.bounding_box()
     mine = np.all((r >= lo) & (r < hi), axis=1)
-    eng = CpuEngine(L, lo, hi, rank, dc.neighbor_table(), rc)
+    skin = float(os.environ["LS1_TEST_SKIN"]) if os.environ.get("LS1_TEST_SKIN") else None
+    eng = CpuEngine(L, lo, hi, rank, dc.neighbor_table(), rc, skin=skin)
     eng.upload(ids[mine], r[mine], v[mine])
     fail = os.environ.get("LS1_TEST_FAIL", "")  # "<rank>:<export_counts call number>:<export|import>"
     if fail and int(fail.split(":")[0]) == rank:

@@ -78,14 +78,16 @@ def _liquid(n, seed=5, rho=0.6, rc=2.5):
 
 
 @pytest.mark.parametrize("world,grid", [(2, "2x1x1"), (4, "2x2x1"), (2, "1x1x2"), (1, "1x1x1+loopback"),
-                                        (2, "2x1x1+loopback")])
+                                        (2, "2x1x1+loopback"), (2, "2x1x1+lists"), (4, "2x2x1+lists"),
+                                        (2, "1x1x2+lists+loopback")])
 def test_gloo_world_matches_single_domain_oracle(world, grid):
     """'+loopback': the periodic images a rank would create locally travel through the transport instead (messages to
     the own rank), the rehearsal mode of bench.py --decomp --loopback."""
-    loopback = grid.endswith("+loopback")
+    loopback = "+loopback" in grid
+    lists = "+lists" in grid  # list mode: halo copies refreshed by position-only messages, collective rebuild decision
     grid = grid.split("+")[0]
     L, r, v = _liquid(5)  # 250 atoms, L ~ 7.5 (>= 2 rc per sub-box edge is NOT required: images handle it)
-    rc, dt, nsteps = 1.8, 0.004, 4
+    rc, dt, nsteps = 1.8, 0.004, (12 if lists else 4)
     ids = np.arange(1, len(r) + 1, dtype=np.uint64)
     comps = inp.ComponentSet([inp.make_component(lj=[(0, 0, 0, 1, 1, 1, rc, 0)])], np.zeros((0, 2)), 1e10)
     orc = Oracle(comps.flat(), rc)
@@ -100,7 +102,7 @@ def test_gloo_world_matches_single_domain_oracle(world, grid):
         np.savez(inp_path, L=L, r=r, v=v, ids=ids, rc=rc)
         out_path = os.path.join(td, "out.npz")
         env = dict(os.environ, LS1_TEST_INPUT=inp_path, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1",
-                   LS1_TEST_LOOPBACK="1" if loopback else "0")
+                   LS1_TEST_LOOPBACK="1" if loopback else "0", LS1_TEST_SKIN="0.08" if lists else "")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                os.path.join(ROOT, "tests", "decomp_worker.py"), out_path, str(nsteps), repr(dt), grid]

@@ -16,7 +16,7 @@ inp = load_pkg("inp")
 
 
 class InProcessCluster:
-    def __init__(self, world, comps, rc, L, ids, r, v, grid=None, kernel=0, cid=None, q=None, D=None):
+    def __init__(self, world, comps, rc, L, ids, r, v, grid=None, kernel=0, cid=None, q=None, D=None, skin=None):
         import torch
         self.torch = torch
         self.world = world
@@ -28,6 +28,8 @@ class InProcessCluster:
             e = engine_mod.DeviceEngine(0)
             e.set_components(comps, rc)
             e.set_option("force_kernel", kernel)
+            if skin:
+                e.set_verlet(skin, force=True)
             e.set_domain(L, lo, hi, dc.rank, dc.neighbor_table())
             m = np.all((r >= lo) & (r < hi), axis=1)
             e.upload(ids[m], np.zeros(m.sum(), np.int32) if cid is None else cid[m], r[m], v[m],
@@ -39,6 +41,7 @@ class InProcessCluster:
         w = decomp.RECORD_DOUBLES[kind]
         counts = [e.export_counts(kind) for e in self.eng]
         bufs = []
+        plan = []  # (source context, destination, directions, records): a position refresh repeats exactly these messages
         for k, e in enumerate(self.eng):
             nbr = self.dcs[k].neighbor_table()
             if k % 2 == 0:  # one message per direction (ls1hip_export_pack)
@@ -49,6 +52,7 @@ class InProcessCluster:
                         t = torch.empty(c * w, dtype=torch.float64, device="cuda:0")
                         e.export_pack(kind, d, t.data_ptr(), c)
                         bufs.append((int(nbr[d]), t, c))
+                        plan.append((k, int(nbr[d]), [d], c))
             else:  # one message per peer (ls1hip_export_pack_dirs), as decomp.HaloExchanger sends them
                 for peer in sorted({int(p) for p in nbr if p >= 0 and p != k}):
                     dirs = [d for d in range(27) if d != 13 and nbr[d] == peer and counts[k][d]]
@@ -57,11 +61,67 @@ class InProcessCluster:
                         t = torch.empty(c * w, dtype=torch.float64, device="cuda:0")
                         e.export_pack_dirs(kind, dirs, t.data_ptr(), c)
                         bufs.append((peer, t, c))
+                        plan.append((k, peer, dirs, c))
         torch.cuda.synchronize()
         for dest, t, c in bufs:
             self.eng[dest].import_records(kind, t.data_ptr(), c)
         for e in self.eng:
             e.import_done(kind)
+        if kind == decomp.HALO:
+            self.halo_plan = plan
+
+    def refresh(self):
+        """list mode: current positions for the halo copies of the last build, through the messages of that build"""
+        torch = self.torch
+        for e in self.eng:
+            e.halo_refresh()
+        bufs = []
+        for k, dest, dirs, c in self.halo_plan:
+            t = torch.empty(c * 3, dtype=torch.float64, device="cuda:0")
+            if len(dirs) == 1:
+                self.eng[k].export_pack(decomp.REFRESH, dirs[0], t.data_ptr(), c)
+            else:
+                self.eng[k].export_pack_dirs(decomp.REFRESH, dirs, t.data_ptr(), c)
+            bufs.append((dest, t, c))
+        torch.cuda.synchronize()
+        for dest, t, c in bufs:
+            self.eng[dest].import_records(decomp.REFRESH, t.data_ptr(), c)
+        for e in self.eng:
+            e.import_done(decomp.REFRESH)
+
+    def run_lists(self, dt, nsteps):
+        """decomp.DistributedSimulation.run_lists with the transport replaced by device-buffer hand-over"""
+        advanced, builds, tot, kin = False, 0, None, None
+        for s in range(nsteps):
+            last = s == nsteps - 1
+            if advanced:
+                rebuild = any([e.verlet_poll() for e in self.eng])  # every context is polled (no short circuit)
+            else:
+                for e in self.eng:
+                    e.kick_drift(dt)
+                rebuild = True
+            advanced = not last
+            fdt = dt if advanced else 0.0
+            if rebuild:
+                builds += 1
+                for e in self.eng:
+                    e.rebin()
+                self.exchange(decomp.LEAVING)
+                for e in self.eng:
+                    e.halo()
+                self.exchange(decomp.HALO)
+                for e in self.eng:
+                    e.verlet_build()
+                res = [e.forces_list(0, fdt, want_macro=last) for e in self.eng]
+            else:
+                for e in self.eng:
+                    e.forces_list(1, fdt)
+                self.refresh()
+                res = [e.forces_list(2, fdt, want_macro=last) for e in self.eng]
+            if last:
+                tot = np.sum(np.array(res), axis=0)
+                kin = np.sum(np.array([e.kick(0.5 * dt)[:2] for e in self.eng]), axis=0)
+        return tot, kin, builds
 
     def forces(self, split=True):
         for e in self.eng:
@@ -373,5 +433,35 @@ def test_leaver_through_a_periodic_face_lands_inside_the_receiver():
     assert np.max(np.abs(dr)) < 1e-11
     assert np.max(np.abs(a["F"] - b["F"])) < 1e-11 * np.max(np.abs(a["F"]))
     assert np.allclose(t1, tm, rtol=1e-11)
+    for e in single.eng + multi.eng:
+        e.close()
+
+
+@pytest.mark.parametrize("world,grid", [(1, None), (2, None), (8, None), (4, (1, 2, 2))])
+def test_list_mode_across_subboxes_equals_single_domain_loop(world, grid):
+    """The decomposed loop in LIST MODE (no migration / re-binning / halo regeneration between rebuilds, halo copies fed
+    by position-only refresh messages, inner-brick pass before the refresh, collective rebuild decision) against the
+    single domain running the ordinary per-step loop: same trajectory over several list lifetimes, hot enough that
+    molecules cross sub-box faces and periodic faces while the lists are alive."""
+    L, r, v = _liquid(16)
+    rc, dt, nsteps = 2.5, 0.002, 30
+    ids = np.arange(1, len(r) + 1, dtype=np.uint64)
+    comps = inp.ComponentSet([inp.make_component(lj=[(0, 0, 0, 1, 1, 1, rc, 0)])], np.zeros((0, 2)), 1e10)
+    single = InProcessCluster(1, comps, rc, L, ids, r, v)
+    single.forces(split=False)
+    for _ in range(nsteps):
+        t1, k1 = single.step(dt)
+    multi = InProcessCluster(world, comps, rc, L, ids, r, v, grid, skin=0.3)
+    multi.forces()
+    tm, km, builds = multi.run_lists(dt, nsteps)
+    assert 2 <= builds <= nsteps // 2, builds
+    a, b = single.gather(), multi.gather()
+    assert np.array_equal(a["ids"], b["ids"])  # nobody lost or duplicated
+    dr = a["r"] - b["r"]
+    dr -= L * np.round(dr / L)
+    assert np.max(np.abs(dr)) < 1e-10
+    assert np.max(np.abs(a["v"] - b["v"])) < 1e-10 * np.max(np.abs(a["v"]))
+    assert np.max(np.abs(a["F"] - b["F"])) < 1e-9 * np.max(np.abs(a["F"]))
+    assert np.allclose(t1, tm, rtol=1e-10) and np.allclose(k1, km, rtol=1e-10)
     for e in single.eng + multi.eng:
         e.close()

@@ -128,6 +128,57 @@ def cpu_baseline(n_per_dim=50, steps=10, budget_s=150):
             "sample": f"oracle/ls1_oracle.c scalar restatement, 1CLJ N={n}, {ksteps} steps, 1 thread"}
 
 
+def live_pmc_traffic(argv_tail, budget_s=240):
+    """HBM traffic of the dominant force kernel measured LIVE: two short child runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace` (separate passes, no other trace domain — the recipe of
+    MI355X_MICROARCH.md), per-launch means, with the guide's gfx950 corrections: both counters are reported in KB and
+    FETCH_SIZE counts half of the bytes of 8 B/lane reads (x2; calibrated in profiles/ on a kernel of known traffic).
+    Returns (bytes per launch, kernel name) or (None, reason).  The children are separate processes started BEFORE they
+    touch the GPU (no exec from a GPU-initialised process)."""
+    import csv
+    import glob
+    import shutil
+    prof = shutil.which("rocprofv3")
+    if not prof:
+        return None, "rocprofv3 not found"
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
+        return None, "this run is itself being profiled (no nested profiler)"
+    per = {}
+    kernel = None
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        td = tempfile.mkdtemp(prefix="ls1pmc_", dir="/tmp")
+        try:
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", td, "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--pmc-child"] + argv_tail
+            env = dict(os.environ, TMPDIR="/tmp")
+            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=budget_s)
+            files = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
+            if res.returncode != 0 or not files:
+                return None, f"rocprofv3 pass {counter} failed (rc {res.returncode})"
+            acc = {}
+            for f in files:
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if r.get("Counter_Name") != counter:
+                            continue
+                        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                        if "k_force_" in name and "reduce" not in name:
+                            acc.setdefault(name, []).append(float(r["Counter_Value"]))
+            if not acc:
+                return None, "no force kernel in the counter trace"
+            # dominant force kernel = most launches (the list build / first-step kernels appear once or a few times)
+            name = max(acc, key=lambda k: len(acc[k]))
+            kernel = kernel or name
+            if name != kernel:
+                return None, "the two passes disagree on the dominant kernel"
+            per[counter] = sum(acc[name]) / len(acc[name])
+        except subprocess.TimeoutExpired:
+            return None, f"rocprofv3 pass {counter} exceeded {budget_s} s"
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
+    return 2.0 * per["FETCH_SIZE"] * 1024.0 + per["WRITE_SIZE"] * 1024.0, kernel
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,7 +199,13 @@ def main():
                     help="diagnostic (with --decomp): route the local periodic images through the RCCL transport "
                          "(send/recv to the own rank): the full multi-GPU exchange path on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="skip the two short rocprofv3 --pmc child passes that measure roofline.traffic live (the figure "
+                         "of the committed profiles/ summary is reported instead)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:  # a counter pass: the same workload, a few steps, nothing else
+        args.steps, args.warmup, args.no_cpu_baseline, args.no_live_pmc = 6, 2, True, True
 
     # stdout carries ONE JSON line: libraries that print to file descriptor 1 (RCCL prints a version banner when the first
     # communicator is created) are sent to stderr for the duration of the run; the result goes to the saved descriptor
@@ -282,6 +339,7 @@ def main():
             js = json.load(fh)
         pm = js["force_kernel"]
         if world == 1 and js.get("molecules") == n_local and e.get_option("cells_in_cutoff") == 1 and \
+                bool(js.get("neighbour_lists")) == (e.get_option("verlet_builds") > 0) and \
                 e.get_option("force_kernel") in (0, 2) and e.get_option("lj_split") == 0 and \
                 abs(pm["algorithmic_bytes_per_launch"] / alg_bytes_per_launch - 1.0) < 0.03:
             traffic = pm["traffic_bytes_per_launch"]
@@ -289,6 +347,17 @@ def main():
                                             "lds_busy_frac_per_cu", "l2_hit_rate") if k in pm}
     except Exception:
         traffic = None
+    traffic_source = f"profiles/{PMC_SUMMARY} (rocprofv3 --pmc passes of this workload, committed)" if traffic is not None else None
+    if rank == 0 and world == 1 and not args.no_live_pmc and not args.decomp:
+        tail = ["--n-per-dim", str(n), "--skin", str(args.skin), "--kernel", str(args.kernel), "--cic", str(args.cic),
+                "--split", str(args.split)] + (["--no-fuse"] if args.no_fuse else [])
+        live, what = live_pmc_traffic(tail)
+        if live is not None:
+            # the child runs 6 timed steps (5 fused + 1 plain launch): same kernel, per-launch mean dominated by the fused form
+            traffic = live
+            traffic_source = f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run, kernel {what}"
+        elif traffic_source is not None:
+            traffic_source += f" [live passes unavailable: {what}]"
     if rank == 0:
         avg_force_s = force_ms / 1e3 / max(force_n, 1)
         achieved = alg_bytes_total / (force_ms / 1e3) / 1e9
@@ -312,6 +381,7 @@ def main():
                                        if fused_on else "separate integrator passes")},
             "roofline": {"bound": "hbm", "kernel": "pair-force traversal (k_force_*)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "avg_launch_ms": avg_force_s * 1e3, "launches": int(force_n),
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "full_step_frac": step_bytes_total / elapsed / 1e9 / HBM_PEAK_GBS},

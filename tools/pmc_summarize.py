@@ -27,7 +27,7 @@ n = bench["config"]["molecules_per_gpu"]
 summary = {"source": "tools/collect_profiles.sh (rocprofv3 --pmc, one pass per counter group, --kernel-trace only), "
                      "bench.py " + " ".join(bench_args) + ", per-launch means",
            "units": {"FETCH_SIZE": "KB as reported", "WRITE_SIZE": "KB as reported", "SQ_*_CYCLES": "quad-cycles"},
-           "molecules": n, "kernels": kern}
+           "molecules": n, "neighbour_lists": bench["config"].get("neighbour_lists") is not None, "kernels": kern}
 # calibration kernel with exactly known traffic (72 B read, 48 B written per molecule): the fused kick pair, or — when
 # the force pass does the integration itself — the plain kick+drift pass of the first step
 kd = [k for k in kern if "k_kick_then_kick_drift" in k] or [k for k in kern if "k_kick_drift" in k]

@@ -190,7 +190,7 @@ def main():
     ap.add_argument("--cic", type=int, default=0, help="cells in cutoff (0 = engine default)")
     ap.add_argument("--split", type=int, default=0, help="lanes per molecule in the LDS LJ kernel (0 = engine default)")
     ap.add_argument("--overlap", type=int, default=-1, help="ls1hip_run halo mode: 0 single pass, 1 overlapped, 2 split sequential")
-    ap.add_argument("--skin", type=float, default=0.3,
+    ap.add_argument("--skin", type=float, default=0.2,
                     help="neighbour-list skin in sigma (list-reuse loop of ls1hip_run, single GPU); 0 = per-step search kernels")
     ap.add_argument("--no-fuse", action="store_true", help="separate integrator passes instead of the fused force pass")
     ap.add_argument("--decomp", action="store_true",

@@ -380,11 +380,18 @@ extern "C" int ls1hip_set_domain(ls1hip_ctx* c, const double global_len[3], cons
 	for (int d = 0; d < 3; ++d)
 		REQUIRE(c, box_max[d] > box_min[d] && box_min[d] >= 0. && box_max[d] <= global_len[d], "bad bounding box");
 	Grid g;
-	if (!grid_init(g, box_min, box_max, c->rc_list, (int)c->opt_cic))
+	int align[3];
+	verlet_brick_shape(align);
+	const bool lists = c->vl_on && c->opt_cic == 1;
+	if (!grid_init(g, box_min, box_max, lists ? c->rc_list : c->rc, (int)c->opt_cic, lists ? align : nullptr))
 		FAIL(c, LS1HIP_EINVAL, "LinkedCells: region too small for the cutoff (or too many cells)");
 	c->g = g;
 	c->my_rank = my_rank;
 	c->has_remote = false;
+	for (int d = 0; d < 3; ++d) {
+		c->dom_min[d] = box_min[d];
+		c->dom_max[d] = box_max[d];
+	}
 	for (int d = 0; d < 3; ++d) c->global_len[d] = global_len[d];
 	for (int sz = -1; sz <= 1; ++sz)
 		for (int sy = -1; sy <= 1; ++sy)
@@ -662,6 +669,23 @@ extern "C" int ls1hip_upload_end(ls1hip_ctx* c) {
 	c->d_ingest = nullptr;
 	c->ingest_bytes = 0;
 	const size_t n = c->ingest_at;  // the announced total is an upper bound (it sized the device arrays)
+	if (c->vl_on && !c->vl_force && c->opt_cic == 1) {
+		// Will the list kernels be able to stage a brick's region?  If the MEAN region already comes close to the capacity
+		// (large skin, dense system) the per-step kernels are the better loop — and they want the reference's r_c grid,
+		// not the r_c + skin one: the domain is set up again without the skin before anything is binned.
+		const double ncell = (double)c->g.box[0] * c->g.box[1] * c->g.box[2];
+		const double mean_region = ncell > 0. ? (double)n / ncell * verlet_region_cells() : 0.;
+		if (mean_region * 1.06 > (double)verlet_region_capacity()) {
+			c->vl_on = false;
+			c->rc_list = c->rc;
+			const double gl[3] = {c->global_len[0], c->global_len[1], c->global_len[2]};
+			const double lo[3] = {c->dom_min[0], c->dom_min[1], c->dom_min[2]}, hi[3] = {c->dom_max[0], c->dom_max[1], c->dom_max[2]};
+			int nbr[27];
+			memcpy(nbr, c->nbr, sizeof(nbr));
+			const int rc2 = ls1hip_set_domain(c, gl, lo, hi, c->my_rank, nbr);
+			if (rc2) return rc2;
+		}
+	}
 	const bool rot = c->h_ct.has_rot;
 	// forces start at zero (a freshly read phase space has F = M = 0: FullMolecule.cpp:44-45)
 	HIPCHK(c, hipMemsetAsync(c->frc.Fx, 0, c->cap_real * sizeof(double), c->stream));
@@ -1215,14 +1239,8 @@ extern "C" int ls1hip_set_verlet(ls1hip_ctx* c, int enabled, double skin) {
 }
 
 // the list-reuse loop serves what the fused per-step loop serves, on a single rank with one cell per cutoff
-static bool can_verlet(const ls1hip_ctx* c) {
-	if (!(c->vl_on && can_fuse(c) && c->g.hw == 1 && !c->has_remote)) return false;
-	// a brick region that does not fit the LDS staging area is evaluated from global memory (correct but slow): if the
-	// MEAN region already comes close to the capacity (large skin, dense system), the per-step kernels are the better loop
-	const double ncell = (double)c->g.box[0] * c->g.box[1] * c->g.box[2];
-	const double mean_region = ncell > 0. ? (double)c->n_real / ncell * verlet_region_cells() : 0.;
-	return c->vl_force || mean_region * 1.06 <= (double)verlet_region_capacity();
-}
+// (a domain whose mean brick region would not fit the LDS staging area has had its lists switched off at upload time)
+static bool can_verlet(const ls1hip_ctx* c) { return c->vl_on && can_fuse(c) && c->g.hw == 1 && !c->has_remote; }
 
 static int ensure_verlet_buffers(ls1hip_ctx* c) {
 	long nbricks;

@@ -138,6 +138,7 @@ struct ls1hip_ctx {
 	// domain
 	ls1::Grid g;
 	double global_len[3] = {0, 0, 0};
+	double dom_min[3] = {0, 0, 0}, dom_max[3] = {0, 0, 0};  // bounding box as passed to ls1hip_set_domain
 	int my_rank = 0;
 	int nbr[27];
 	double shift[27][3];  // position shift applied to a copy/leaver sent in direction d
@@ -309,6 +310,7 @@ bool launch_force_verlet(const ForceParams& p, hipStream_t s, uint32_t* nblocks,
 void verlet_geometry(const Grid& g, long* nbricks, size_t* words_per_brick, size_t* tiles_per_brick);
 int verlet_region_capacity();  // molecules of a brick's region the list kernels can stage in LDS
 int verlet_region_cells();
+void verlet_brick_shape(int shape[3]);  // cells per brick edge of the list kernels
 // brick-tiled multi-site kernel (kernels_force_ms.hip); returns false if it cannot handle the configuration
 bool launch_force_ms(const ForceParams& p, bool with_vi, bool has_rot, hipStream_t s, uint32_t* nblocks, size_t partials_cap,
 					 double mean_per_cell, BrickLists* bl);

@@ -19,7 +19,13 @@ struct Grid {
 	double bmin[3], bmax[3], clen[3], crec[3];
 };
 
-inline bool grid_init(Grid& g, const double bmin[3], const double bmax[3], double cutoff, int cells_in_cutoff) {
+// align (optional, list mode): brick edge per dimension — the cell count is rounded DOWN to a multiple of it (cells only get
+// longer, never shorter than the cutoff) when that costs at most 1.5 % in cell length: partial bricks at the upper faces
+// otherwise run half-empty workgroups (measured on the 10^8 box: 186 -> 184 cells per dimension, 46 full bricks instead of
+// 46.5: 7.36 -> 7.68e9 updates/s; on the 10^7 box 86 -> 84 cells makes the cells 2.4 % longer and the staged regions 7 %
+// larger, which costs more than the half-empty bricks: 7.42 -> 6.86e9, hence the limit)
+inline bool grid_init(Grid& g, const double bmin[3], const double bmax[3], double cutoff, int cells_in_cutoff,
+					  const int* align = nullptr) {
 	const float rc = (float)(cutoff / cells_in_cutoff);  // float on purpose, LinkedCells.cpp:152
 	g.hw = cells_in_cutoff;
 	long n = 1;
@@ -27,6 +33,10 @@ inline bool grid_init(Grid& g, const double bmin[3], const double bmax[3], doubl
 		g.bmin[d] = bmin[d];
 		g.bmax[d] = bmax[d];
 		g.box[d] = (int)floor((bmax[d] - bmin[d]) / rc);
+		if (align && align[d] > 1) {
+			const int a = (g.box[d] / align[d]) * align[d];
+			if (a >= align[d] && (double)a >= 0.985 * (double)g.box[d]) g.box[d] = a;
+		}
 		if (g.box[d] < 1) return false;  // reference: "region too small" -> exit(1), LinkedCells.cpp:161-164
 		g.dims[d] = g.box[d] + 2 * g.hw;
 		const double diff = bmax[d] - bmin[d];

@@ -60,6 +60,11 @@ static_assert(2 * VCAPS * 8 < 65536, "y / z are addressed as constant offsets fr
 
 int verlet_region_capacity() { return VCAPJ; }
 int verlet_region_cells() { return VNRC; }
+void verlet_brick_shape(int shape[3]) {
+	shape[0] = VBX;
+	shape[1] = VBY;
+	shape[2] = VBZ;
+}
 
 void verlet_geometry(const Grid& g, long* nbricks, size_t* words_per_brick, size_t* tiles_per_brick) {
 	const long nbx = (g.box[0] + VBX - 1) / VBX, nby = (g.box[1] + VBY - 1) / VBY, nbz = (g.box[2] + VBZ - 1) / VBZ;

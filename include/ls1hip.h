@@ -253,6 +253,12 @@ int ls1hip_set_verlet(ls1hip_ctx* ctx, int enabled, double skin);
 #define LS1HIP_REFRESH_DOUBLES 3
 int ls1hip_verlet_build(ls1hip_ctx* ctx);
 int ls1hip_halo_refresh(ls1hip_ctx* ctx);
+/* Single-rank convenience: LinkedCells::update + DomainDecompBase::balanceAndExchange + updateMoleculeCaches in one call, list-aware.
+ * While lists are alive and the displacement bound allows it (every drifting pass — the fused force pass as well as
+ * ls1hip_kick_drift / ls1hip_kick_then_kick_drift — advances the bound on the device) only the halo positions are refreshed;
+ * otherwise ls1hip_rebin + ls1hip_halo (+ ls1hip_verlet_build in list mode).  *rebuilt (may be NULL): 1 if it re-binned.
+ * Follow with ls1hip_forces_list (list mode) or ls1hip_forces. */
+int ls1hip_update(ls1hip_ctx* ctx, int* rebuilt);
 int ls1hip_forces_list(ls1hip_ctx* ctx, int which, double dt, double* upot, double* virial);
 int ls1hip_verlet_poll(ls1hip_ctx* ctx, int* need_rebuild);
 

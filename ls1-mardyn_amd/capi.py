@@ -56,6 +56,7 @@ SYMBOLS = {
     "ls1hip_set_verlet": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     "ls1hip_verlet_build": (C.c_int, [C.c_void_p]),
     "ls1hip_halo_refresh": (C.c_int, [C.c_void_p]),
+    "ls1hip_update": (C.c_int, [C.c_void_p, _ip]),
     "ls1hip_forces_list": (C.c_int, [C.c_void_p, C.c_int, C.c_double, _dp, _dp]),
     "ls1hip_verlet_poll": (C.c_int, [C.c_void_p, _ip]),
     "ls1hip_run": (C.c_int, [C.c_void_p, C.c_double, C.c_ulong, _dp]),

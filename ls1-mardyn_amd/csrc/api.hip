@@ -106,7 +106,6 @@ static void free_mol(ls1hip_ctx* c) {
 	dfree(c->alt_x); dfree(c->alt_y); dfree(c->alt_z);
 	dfree(c->d_vl_words); dfree(c->d_vl_nw);
 	c->vl_words_cap = c->vl_tiles_cap = 0;
-	c->vl_valid = false;
 	c->pos_x = c->pos_y = c->pos_z = nullptr;
 	dfree(c->d_key); dfree(c->d_rank); dfree(c->d_perm); dfree(c->d_ckey); dfree(c->d_idk);
 	dfree(c->d_partials);
@@ -237,6 +236,7 @@ extern "C" int ls1hip_get_option(const ls1hip_ctx* c, const char* name, long* v)
 	else if (n == "can_fuse_integration") *v = can_fuse(c) ? 1 : 0;
 	else if (n == "last_force_kernel") *v = c->last_force_kernel;
 	else if (n == "verlet_lists") *v = c->vl_on ? 1 : 0;
+	else if (n == "verlet_ready") *v = c->vl_ready ? 1 : 0;
 	else if (n == "verlet_builds") *v = (long)c->vl_builds;
 	else if (n == "verlet_steps") *v = (long)c->vl_steps;
 	else return LS1HIP_EINVAL;
@@ -587,7 +587,8 @@ extern "C" int ls1hip_upload_begin(ls1hip_ctx* c, size_t n) {
 	c->n_halo = 0;
 	c->binned = c->halo_valid = c->forces_valid = false;
 	c->pos_x = c->pos_y = c->pos_z = nullptr;
-	c->vl_valid = false;
+	c->vl_ready = false;
+	c->vl_bound_pending = false;
 	c->fused_split = 0;
 	return LS1HIP_OK;
 }
@@ -803,7 +804,8 @@ static int do_rebin_finish(ls1hip_ctx* c, uint32_t n_in) {
 	HIPCHK(c, hipGetLastError());
 	c->cur ^= 1;
 	c->pos_x = c->pos_y = c->pos_z = nullptr;
-	c->vl_valid = false;
+	c->vl_ready = false;  // a new binning: the neighbour lists (offsets into the old staging order) are void
+	c->vl_bound_pending = false;
 	c->binned = true;
 	c->halo_valid = false;
 	c->forces_valid = false;
@@ -1026,7 +1028,7 @@ extern "C" int ls1hip_forces_kick_drift(ls1hip_ctx* c, int which, double dt, dou
 		// velocities are at t + dt/2 of the NEXT step and the advanced positions wait in the force arrays for ls1hip_rebin
 		c->fused_split = 0;
 		c->pos_x = c->frc.Fx; c->pos_y = c->frc.Fy; c->pos_z = c->frc.Fz;
-		c->vl_valid = false;
+		c->vl_ready = false;
 		c->binned = false;
 		c->halo_valid = false;
 		c->forces_valid = false;
@@ -1062,7 +1064,29 @@ static IntegArgs integ_args(ls1hip_ctx* c, double dt) {
 	a.n_cap = (uint32_t)c->n_real;
 	a.has_rot = c->h_ct.has_rot;
 	a.dt = dt;
+	a.vmax_part = nullptr;
 	return a;
+}
+
+// List mode: a separate kick + drift pass moves the molecules in place in the CURRENT position buffer, reports the
+// maximum drift speed and advances the displacement bound (the lists stay valid; the next ls1hip_update decides).
+static IntegArgs integ_args_lists(ls1hip_ctx* c, double dt) {
+	IntegArgs a = integ_args(c, dt);
+	if (c->pos_x) {
+		a.mol.x = c->pos_x;
+		a.mol.y = c->pos_y;
+		a.mol.z = c->pos_z;
+	}
+	a.vmax_part = c->d_partials;
+	return a;
+}
+static int track_unfused_drift(ls1hip_ctx* c, double dt) {
+	const uint32_t nb = ((uint32_t)c->n_real + 255u) / 256u;
+	launch_bound_update(c->d_cnt, c->d_partials, nb, dt, 0.5 * c->vl_skin, c->vl_fresh, ++c->vl_seq, c->d_flag, c->stream);
+	HIPCHK(c, hipGetLastError());
+	c->vl_fresh = false;
+	c->vl_bound_pending = true;
+	return LS1HIP_OK;
 }
 
 extern "C" int ls1hip_kick_drift(ls1hip_ctx* c, double dt) {
@@ -1070,14 +1094,19 @@ extern "C" int ls1hip_kick_drift(ls1hip_ctx* c, double dt) {
 	REQUIRE(c, c->cap_real, "no molecules uploaded");
 	REQUIRE(c, !c->fused_split, "a fused inner pass is waiting for its boundary pass");
 	REQUIRE(c, !c->pos_x || c->forces_valid, "positions were already advanced by ls1hip_forces_kick_drift (call ls1hip_rebin)");
-	if (c->pos_x) {  // list-reuse run that ended with an unfused step: the positions live in the second buffer
+	HIPCHK(c, hipSetDevice(c->device));
+	if (c->pos_x && !c->vl_ready) {  // positions parked in another buffer and no lists to keep alive
 		int rcm = materialise_positions(c);
 		if (rcm) return rcm;
 	}
-	c->vl_valid = false;
-	HIPCHK(c, hipSetDevice(c->device));
 	TimedScope ts(c, c->t_integrate);
-	launch_kick_drift(integ_args(c, dt), c->stream);
+	if (c->vl_ready) {
+		launch_kick_drift(integ_args_lists(c, dt), c->stream);
+		int rcb = track_unfused_drift(c, dt);
+		if (rcb) return rcb;
+	} else {
+		launch_kick_drift(integ_args(c, dt), c->stream);
+	}
 	HIPCHK(c, hipGetLastError());
 	c->binned = false;
 	c->halo_valid = false;
@@ -1090,13 +1119,18 @@ extern "C" int ls1hip_kick_then_kick_drift(ls1hip_ctx* c, double dt) {
 	REQUIRE(c, c->forces_valid, "forces are not valid (call ls1hip_forces)");
 	REQUIRE(c, !c->thermostat_on, "with the device thermostat the two half kicks are separate passes (kick, scale, kick_drift)");
 	HIPCHK(c, hipSetDevice(c->device));
-	if (c->pos_x) {
+	if (c->pos_x && !c->vl_ready) {
 		int rcm = materialise_positions(c);
 		if (rcm) return rcm;
 	}
-	c->vl_valid = false;
 	TimedScope ts(c, c->t_integrate);
-	launch_kick_then_kick_drift(integ_args(c, dt), c->stream);
+	if (c->vl_ready) {
+		launch_kick_then_kick_drift(integ_args_lists(c, dt), c->stream);
+		int rcb = track_unfused_drift(c, dt);
+		if (rcb) return rcb;
+	} else {
+		launch_kick_then_kick_drift(integ_args(c, dt), c->stream);
+	}
 	HIPCHK(c, hipGetLastError());
 	c->binned = false;
 	c->halo_valid = false;
@@ -1234,13 +1268,13 @@ extern "C" int ls1hip_set_verlet(ls1hip_ctx* c, int enabled, double skin) {
 	c->vl_force = enabled == 2;
 	c->vl_skin = enabled ? skin : 0.;
 	c->rc_list = c->rc + c->vl_skin;
-	c->vl_valid = false;
+	c->vl_ready = false;
 	return LS1HIP_OK;
 }
 
 // the list-reuse loop serves what the fused per-step loop serves, on a single rank with one cell per cutoff
 // (a domain whose mean brick region would not fit the LDS staging area has had its lists switched off at upload time)
-static bool can_verlet(const ls1hip_ctx* c) { return c->vl_on && can_fuse(c) && c->g.hw == 1 && !c->has_remote; }
+static bool can_verlet(const ls1hip_ctx* c) { return c->vl_on && c->g.hw == 1 && !c->has_remote; }
 
 static int ensure_verlet_buffers(ls1hip_ctx* c) {
 	long nbricks;
@@ -1292,6 +1326,7 @@ static int verlet_refresh_halo(ls1hip_ctx* c) {
 	double *x = c->pos_x ? c->pos_x : m.x, *y = c->pos_x ? c->pos_y : m.y, *z = c->pos_x ? c->pos_z : m.z;
 	launch_halo_refresh(a, x, y, z, x, y, z, c->stream);
 	HIPCHK(c, hipGetLastError());
+	c->halo_valid = true;
 	return LS1HIP_OK;
 }
 
@@ -1321,11 +1356,14 @@ static int verlet_poll_rebuild(ls1hip_ctx* c, bool* need) {
 }
 
 // ---- list mode, piecewise (multi-rank loops drive these; ls1hip_run is the single-rank loop) -------------------------------
-static bool can_verlet_piecewise(const ls1hip_ctx* c) { return c->vl_on && can_fuse(c) && c->g.hw == 1; }
+// lists serve the single-centre LJ fast path on a one-cell-per-cutoff grid; FUSED list passes additionally need can_fuse()
+static bool can_list(const ls1hip_ctx* c) {
+	return c->vl_on && c->one_clj && c->opt_force_kernel != LS1HIP_FK_GENERIC && !c->opt_vi && !c->opt_count_pairs && c->g.hw == 1;
+}
 
 extern "C" int ls1hip_verlet_build(ls1hip_ctx* c) {
 	if (!c) return LS1HIP_EINVAL;
-	REQUIRE(c, can_verlet_piecewise(c), "neighbour lists need ls1hip_set_verlet, the single-centre LJ fast path and one cell per cutoff");
+	REQUIRE(c, can_list(c), "neighbour lists need ls1hip_set_verlet, the single-centre LJ fast path and one cell per cutoff");
 	REQUIRE(c, c->binned && c->halo_valid, "neighbour lists are built from binned molecules and a populated halo");
 	REQUIRE(c, !c->inner_in_flight && !c->fused_split, "a split force pass is in flight");
 	HIPCHK(c, hipSetDevice(c->device));
@@ -1370,6 +1408,7 @@ extern "C" int ls1hip_forces_list(ls1hip_ctx* c, int which, double dt, double* u
 	REQUIRE(c, which == 1 || c->halo_valid, "halo positions are not current (ls1hip_halo_refresh / import_done(2))");
 	REQUIRE(c, dt >= 0., "dt must be >= 0 (0: forces only, > 0: fused with kick + kick + drift)");
 	const bool fuse = dt > 0.;
+	REQUIRE(c, !fuse || can_fuse(c), "fused list passes: no per-molecule virial, no device thermostat");
 	REQUIRE(c, (fuse && which == 2) ? c->fused_split == 1 : c->fused_split == 0,
 			"fused list passes must be which=0, or which=1 followed by which=2");
 	HIPCHK(c, hipSetDevice(c->device));
@@ -1396,7 +1435,6 @@ extern "C" int ls1hip_forces_list(ls1hip_ctx* c, int which, double dt, double* u
 		c->pos_z = in_alt ? nullptr : c->alt_z;
 		c->fused_split = 0;
 		c->vl_fresh = false;
-		c->vl_valid = true;
 		c->vl_bound_pending = true;
 		c->halo_valid = false;
 		c->forces_valid = false;
@@ -1423,6 +1461,27 @@ extern "C" int ls1hip_verlet_poll(ls1hip_ctx* c, int* need_rebuild) {
 	return LS1HIP_OK;
 }
 
+// LinkedCells::update + DomainDecompBase::balanceAndExchange + updateMoleculeCaches of a SINGLE-RANK domain in one call, list-aware:
+// while neighbour lists are alive and the displacement bound allows it, the molecules keep their cells and the halo copies
+// their slots — only the halo positions are refreshed; otherwise re-bin, regenerate the halo and (list mode) rebuild.
+extern "C" int ls1hip_update(ls1hip_ctx* c, int* rebuilt) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, !c->has_remote, "ls1hip_update serves single-rank domains (multi-rank: rebin / exchange / halo / verlet_build)");
+	REQUIRE(c, c->have_domain && c->cap_real, "no molecules uploaded");
+	HIPCHK(c, hipSetDevice(c->device));
+	int rc;
+	bool rebuild = true;
+	if (c->vl_ready && can_list(c)) {
+		rebuild = false;
+		if (c->vl_bound_pending && (rc = verlet_poll_rebuild(c, &rebuild))) return rc;
+	}
+	if (rebuilt) *rebuilt = rebuild ? 1 : 0;
+	if (!rebuild) return verlet_refresh_halo(c);
+	if ((rc = ls1hip_rebin(c)) || (rc = ls1hip_halo(c))) return rc;
+	if (can_list(c)) return ls1hip_verlet_build(c);
+	return LS1HIP_OK;
+}
+
 extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double* out6) {
 	if (!c) return LS1HIP_EINVAL;
 	REQUIRE(c, !c->has_remote, "ls1hip_run drives single-rank domains only (use the piecewise calls with a transport)");
@@ -1431,7 +1490,8 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 	// Between two steps of an NVE run on the LJ fast path the force pass does the integration itself (fused mode, the
 	// reference's reduced-memory scheme); the last step is unfused so that F and the kinetic sums are available.
 	const bool fuse = c->opt_fuse && can_fuse(c);
-	const bool verlet = fuse && can_verlet(c);
+	// neighbour-list loop (fused or not: NVT and unfused NVE steps advance the displacement bound in their kick + drift pass)
+	const bool verlet = can_verlet(c) && can_list(c);
 	bool advanced = false;  // the previous force pass already did kick + kick + drift
 	// step log: one row {U_pot, virial, sum m v^2, sum I w^2, N, rotDOF} per step, written by the reductions on the device
 	if (!c->d_steplog) {
@@ -1465,45 +1525,12 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 			// post-force kick of step s-1 fused with the pre-force kick+drift of step s (same F, one pass)
 			if ((rc = ls1hip_kick_then_kick_drift(c, dt))) return rc;
 		}
-		const bool was_advanced = advanced;
 		advanced = fuse && s + 1 < nsteps;
 		if (verlet) {
-			// neighbour-list loop: the lists, the binning and the halo slots live until the displacement bound of the
-			// molecules (accumulated on the device) exceeds skin / 2; then re-bin, regenerate the halo, rebuild the lists
-			bool rebuild = true;
-			if (was_advanced && c->vl_valid && (rc = verlet_poll_rebuild(c, &rebuild))) return rc;
-			if (rebuild) {
-				if ((rc = ls1hip_rebin(c)) || (rc = ls1hip_halo(c)) || (rc = verlet_build(c))) return rc;
-			} else {
-				if ((rc = verlet_refresh_halo(c))) return rc;
-			}
-			{
-				TimedScope ts(c, c->t_force);
-				ForcePass fp;
-				fp.which = 0;
-				fp.fuse = advanced;
-				fp.dt = dt;
-				fp.vl = 2;
-				fp.lists_rebuilt = rebuild;
-				if ((rc = launch_forces(c, fp))) return rc;
-			}
-			c->vl_steps++;
-			if (advanced) {
-				// velocities are at t + dt/2 of the next step; the advanced positions wait in the other position buffer
-				const bool in_alt = c->pos_x == c->alt_x;
-				const MolSoA& m = c->mol[c->cur];
-				c->pos_x = in_alt ? nullptr : c->alt_x;
-				c->pos_y = in_alt ? nullptr : c->alt_y;
-				c->pos_z = in_alt ? nullptr : c->alt_z;
-				(void)m;
-				c->vl_valid = true;
-				c->halo_valid = false;
-				c->forces_valid = false;
-			} else {
-				c->forces_valid = true;
-				c->halo_valid = true;
-				c->vl_valid = false;  // an unfused pass does not advance the displacement bound
-			}
+			// the lists, the binning and the halo slots live until the displacement bound of the molecules (accumulated on
+			// the device by whichever pass drifts them) exceeds skin / 2; then re-bin, regenerate the halo, rebuild the lists
+			if ((rc = ls1hip_update(c, nullptr))) return rc;
+			rc = ls1hip_forces_list(c, 0, advanced ? dt : 0., nullptr, nullptr);
 		} else if (c->opt_overlap_halo == 2) {
 			if ((rc = ls1hip_rebin(c))) return rc;
 			// halo first, then the inner and the boundary cells as two passes of the same stream

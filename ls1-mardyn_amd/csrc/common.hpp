@@ -341,7 +341,10 @@ struct IntegArgs {
 	uint32_t n_cap;
 	bool has_rot;
 	double dt;
+	double* vmax_part;  // list mode: per-workgroup max |v_drift|^2 of a kick + drift pass (null otherwise)
 };
+void launch_bound_update(DevCounters* cnt, const double* vmax_part, uint32_t nblocks, double dt, double limit, bool fresh, uint32_t seq,
+						 volatile uint32_t* flag, hipStream_t s);
 void launch_kick_drift(const IntegArgs& a, hipStream_t s);
 void launch_kick(const IntegArgs& a, hipStream_t s, uint32_t* nblocks);
 void launch_kick_then_kick_drift(const IntegArgs& a, hipStream_t s);

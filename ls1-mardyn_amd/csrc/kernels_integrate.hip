@@ -17,10 +17,24 @@ __device__ __forceinline__ void q_diff(const double q[4], V3 w, double dq[4]) {
 	dq[3] = .5 * (-q[2] * w.x + q[1] * w.y + q[0] * w.z);
 }
 
+// list mode: the drift speed of this pass bounds how far any molecule moves in it; block maximum -> vmax_part[block]
+__device__ __forceinline__ void block_vmax(double v2, double* vmax_part) {
+	__shared__ double red[ITPB / 64];
+	for (int o = 32; o > 0; o >>= 1) v2 = fmax(v2, __shfl_down(v2, o));
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v2;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		double m = 0.;
+		for (int i = 0; i < ITPB / 64; ++i) m = fmax(m, red[i]);
+		vmax_part[blockIdx.x] = m;
+	}
+}
+
 template <bool HAS_ROT>
 __global__ void __launch_bounds__(ITPB) k_kick_drift(IntegArgs a) {
 	const uint32_t p = blockIdx.x * ITPB + threadIdx.x;
-	if (p >= a.cnt->n_real) return;
+	double v2 = 0.;
+	if (p < a.cnt->n_real) {
 	const double dt = a.dt, dt_halve = .5 * dt;
 	const int c = HAS_ROT ? a.mol.cid[p] : (a.ct->ncomp > 1 ? a.mol.cid[p] : 0);
 	const double dtInv2m = dt_halve / a.ct->mass[c];
@@ -33,6 +47,7 @@ __global__ void __launch_bounds__(ITPB) k_kick_drift(IntegArgs a) {
 	a.mol.x[p] += dt * vx;
 	a.mol.y[p] += dt * vy;
 	a.mol.z[p] += dt * vz;
+	v2 = vx * vx + vy * vy + vz * vz;
 	if (HAS_ROT) {
 		double q[4] = {a.mol.q0[p], a.mol.q1[p], a.mol.q2[p], a.mol.q3[p]};
 		V3 D = {a.mol.Dx[p], a.mol.Dy[p], a.mol.Dz[p]};
@@ -60,6 +75,8 @@ __global__ void __launch_bounds__(ITPB) k_kick_drift(IntegArgs a) {
 		a.mol.Dy[p] = D.y;
 		a.mol.Dz[p] = D.z;
 	}
+	}
+	if (a.vmax_part) block_vmax(v2, a.vmax_part);  // every thread of the workgroup arrives here (one barrier inside)
 }
 
 // Inside ls1hip_run two consecutive Leapfrog events touch the same arrays back to back: upd_postF of step n
@@ -69,7 +86,8 @@ __global__ void __launch_bounds__(ITPB) k_kick_drift(IntegArgs a) {
 template <bool HAS_ROT>
 __global__ void __launch_bounds__(ITPB) k_kick_then_kick_drift(IntegArgs a) {
 	const uint32_t p = blockIdx.x * ITPB + threadIdx.x;
-	if (p >= a.cnt->n_real) return;
+	double v2 = 0.;
+	if (p < a.cnt->n_real) {
 	const double dt = a.dt, dt_halve = .5 * dt;
 	const int c = HAS_ROT ? a.mol.cid[p] : (a.ct->ncomp > 1 ? a.mol.cid[p] : 0);
 	const double dtInv2m = dt_halve / a.ct->mass[c];
@@ -83,6 +101,7 @@ __global__ void __launch_bounds__(ITPB) k_kick_then_kick_drift(IntegArgs a) {
 	a.mol.vx[p] = vx;
 	a.mol.vy[p] = vy;
 	a.mol.vz[p] = vz;
+	v2 = vx * vx + vy * vy + vz * vz;
 	a.mol.x[p] += dt * vx;
 	a.mol.y[p] += dt * vy;
 	a.mol.z[p] += dt * vz;
@@ -114,6 +133,8 @@ __global__ void __launch_bounds__(ITPB) k_kick_then_kick_drift(IntegArgs a) {
 		a.mol.Dy[p] = D.y;
 		a.mol.Dz[p] = D.z;
 	}
+	}
+	if (a.vmax_part) block_vmax(v2, a.vmax_part);
 }
 
 void launch_kick_then_kick_drift(const IntegArgs& a, hipStream_t s) {
@@ -246,6 +267,32 @@ void launch_scale(const IntegArgs& a, double beta_trans, double beta_rot, bool f
 	const dim3 grid((a.n_cap + ITPB - 1) / ITPB);
 	if (a.has_rot) hipLaunchKernelGGL(k_scale<true>, grid, dim3(ITPB), 0, s, a, beta_trans, beta_rot, from_device);
 	else hipLaunchKernelGGL(k_scale<false>, grid, dim3(ITPB), 0, s, a, beta_trans, beta_rot, from_device);
+}
+
+// List mode, unfused drifts: advance the displacement bound by dt * max |v| of this pass and publish the rebuild flag
+// (the fused force passes do the same inside k_force_reduce2).
+__global__ void __launch_bounds__(256) k_bound_update(DevCounters* cnt, const double* vmax_part, uint32_t nblocks, double dt, double limit,
+												  int fresh, uint32_t seq, volatile uint32_t* flag) {
+	double m = 0.;
+	for (uint32_t b = threadIdx.x; b < nblocks; b += 256) m = fmax(m, vmax_part[b]);
+	__shared__ double red[4];
+	for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o));
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+		const double b = (fresh ? 0. : cnt->vl_bound) + dt * sqrt(m);
+		cnt->vl_bound = b;
+		if (flag) {
+			__threadfence_system();
+			*flag = (seq << 1) | (b > limit ? 1u : 0u);
+			__threadfence_system();
+		}
+	}
+}
+void launch_bound_update(DevCounters* cnt, const double* vmax_part, uint32_t nblocks, double dt, double limit, bool fresh, uint32_t seq,
+						 volatile uint32_t* flag, hipStream_t s) {
+	hipLaunchKernelGGL(k_bound_update, dim3(1), dim3(256), 0, s, cnt, vmax_part, nblocks, dt, limit, fresh ? 1 : 0, seq, flag);
 }
 
 void launch_kin_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, hipStream_t s, double target_T, double* log) {

@@ -233,6 +233,12 @@ class DeviceEngine:
     def verlet_build(self):
         self._chk(self.lib.ls1hip_verlet_build(self.ctx))
 
+    def update(self) -> bool:
+        """update + exchange + caches of a single-rank domain, list-aware; True if it re-binned (see ls1hip_update)"""
+        n = C.c_int()
+        self._chk(self.lib.ls1hip_update(self.ctx, C.byref(n)))
+        return bool(n.value)
+
     def halo_refresh(self):
         self._chk(self.lib.ls1hip_halo_refresh(self.ctx))
 

@@ -153,6 +153,13 @@ void LinkedCellsHip::uploadFromMirror() {
 										 sim->getLJCutoff())))
 		die("ls1hip_set_components", rc);
 	if ((rc = ls1hip_set_option(_ctx, "cells_in_cutoff", _mirror.getHaloWidthNumCells()))) die("ls1hip_set_option", rc);
+	// neighbour lists with a skin (ls1hip_set_verlet): on by default with 8 % of the cutoff, LS1HIP_SKIN=<length> overrides,
+	// LS1HIP_SKIN=0 keeps the reference's search-every-step scheme.  The engine falls back by itself where lists do not apply
+	// (multi-site components, two cells per cutoff, regions beyond its staging capacity).
+	_skin = 0.08 * sim->getcutoffRadius();
+	if (const char* e = getenv("LS1HIP_SKIN")) _skin = atof(e);
+	if (_mirror.getHaloWidthNumCells() != 1) _skin = 0.;
+	if ((rc = ls1hip_set_verlet(_ctx, _skin > 0. ? 1 : 0, _skin))) die("ls1hip_set_verlet", rc);
 	double glen[3], bmin[3], bmax[3];
 	int nbr[27];
 	for (int d = 0; d < 3; ++d) {
@@ -191,15 +198,14 @@ void LinkedCellsHip::update() {
 		_mirror.update();
 		uploadFromMirror();
 	}
-	int rc = ls1hip_rebin(_ctx);
-	if (rc) die("ls1hip_rebin", rc);
+	// list-aware: re-bin + halo (+ list build), or — while the lists are alive — only a refresh of the halo positions
+	int rc = ls1hip_update(_ctx, nullptr);
+	if (rc) die("ls1hip_update", rc);
 	_inExchange = true;
 }
 
 void LinkedCellsHip::updateMoleculeCaches() {
-	_inExchange = false;
-	int rc = ls1hip_halo(_ctx);
-	if (rc) die("ls1hip_halo", rc);
+	_inExchange = false;  // (the halo was populated / refreshed by ls1hip_update)
 	if (_mirrorFresh) _mirror.updateMoleculeCaches();  // keeps calcFM on mirror molecules (prepare_start) well defined
 }
 void LinkedCellsHip::updateInnerMoleculeCaches() {}
@@ -212,7 +218,10 @@ void LinkedCellsHip::deleteOuterParticles() {
 void LinkedCellsHip::deviceForces(int which) {
 	double upot = 0., virial = 0.;
 	const bool want = which != 1;
-	int rc = ls1hip_forces(_ctx, which, want ? &upot : nullptr, want ? &virial : nullptr);
+	long lists = 0;
+	ls1hip_get_option(_ctx, "verlet_ready", &lists);
+	int rc = lists ? ls1hip_forces_list(_ctx, which, 0., want ? &upot : nullptr, want ? &virial : nullptr)
+				   : ls1hip_forces(_ctx, which, want ? &upot : nullptr, want ? &virial : nullptr);
 	if (rc) die("ls1hip_forces", rc);
 	if (want) {
 		// what VectorizedCellProcessor::endTraversal publishes (VectorizedCellProcessor.cpp:155-156)
@@ -346,6 +355,14 @@ void LeapfrogHip::eventForcesCalculated(ParticleContainer* moleculeContainer, Do
 	if (const char* e = getenv("LS1HIP_MIRROR_SYNC_INTERVAL")) interval = atol(e);
 	Simulation* sim = global_simulation;
 	bool last = sim->getSimulationStep() >= sim->getNumTimesteps();
+	if (last) {
+		long on = 0, builds = 0, evals = 0;
+		ls1hip_get_option(ctx, "verlet_lists", &on);
+		ls1hip_get_option(ctx, "verlet_builds", &builds);
+		ls1hip_get_option(ctx, "verlet_steps", &evals);
+		global_log->info() << "LinkedCellsHip: neighbour lists " << (on ? "on" : "off") << ": " << builds << " builds for " << evals
+						   << " list force evaluations" << std::endl;
+	}
 	if (const char* e = getenv("LS1HIP_MIRROR_SYNC_FINAL"))  // "0": nothing will iterate the molecules after the run (no final
 		if (atoi(e) == 0) last = false;                      // checkpoint, no finishing plugin): skip the O(N) host refill
 	if (last || (interval > 0 && _stepsDone % (unsigned long)interval == 0)) cont->syncMirrorFromDevice();

@@ -98,6 +98,7 @@ private:
 
 	LinkedCells _mirror;  // host mirror: the reference's own container (all host-side semantics)
 	ls1hip_ctx* _ctx = nullptr;
+	double _skin = 0.;          // neighbour-list skin handed to ls1hip_set_verlet (0: search every step)
 	bool _uploaded = false;     // the device holds the molecule set
 	bool _mirrorFresh = true;   // the mirror holds the current molecule set
 	bool _hostDirty = true;     // molecules were added / removed through the host interface since the last upload

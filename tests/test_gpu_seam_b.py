@@ -79,6 +79,12 @@ def test_reference_driver_with_device_container_and_integrator(tmp_path, case):
     assert "LinkedCellsHip: device-resident container" in out["hipB"][1] and "LeapfrogHip" in out["hipB"][1]
     n = min(len(ref), len(hip))
     assert n >= steps
+    m = re.search(r"neighbour lists (on|off): (\d+) builds for (\d+) list force evaluations", out["hipB"][1])
+    assert m
+    if case == "1clj_generated":  # single-site LJ: the adapter's default is the list loop (skin 0.08 rc), rebuilt on demand
+        assert m.group(1) == "on" and int(m.group(3)) >= steps and 1 <= int(m.group(2)) < steps
+    if case == "ethane_inp":      # multi-site: the engine keeps the search-every-step kernels by itself
+        assert int(m.group(3)) == 0
     # the driver prints 6 significant digits
     assert np.allclose(hip[:n], ref[:n], rtol=2e-5, atol=1e-12), (ref[:n], hip[:n])
     # final checkpoint: written by the reference's writer iterating OUR container (mirror synced from the device)
@@ -101,8 +107,9 @@ def test_reference_driver_with_device_container_and_integrator(tmp_path, case):
 def test_device_container_speed_line_in_the_reference_driver(tmp_path):
     """The reference's own `Simulation speed` line (MarDyn.cpp:253-266) with the device container at a size where the
     per-run host work (generator, initial upload, final mirror sync) no longer dominates: N = 2*100^3, 100 steps, NVT as
-    every shipped config.  The per-step path of this seam is the piecewise one (kick-drift, re-bin, halo, forces, kick with
-    the driver's host-side global values in between); the fused / list-reuse loop needs the loop handed over (ls1hip_run)."""
+    every shipped config.  The per-step path of this seam is the piecewise one (kick-drift, update, forces, kick with the
+    driver's host-side global values in between), list-aware by default (LS1HIP_SKIN, 0 = search every step); the fused
+    epilogue needs the loop handed over (ls1hip_run)."""
     N = 2 * 100 ** 3
     L = (N / 0.785302672) ** (1 / 3)
     cfg = HEAD.format(dt=0.002, steps=100, temp=0.95, L=repr(L), rc=2.5, components=LJ1,
@@ -110,10 +117,19 @@ def test_device_container_speed_line_in_the_reference_driver(tmp_path):
                                  '<density>0.785302672</density><binaryMixture>false</binaryMixture></generator>')
     (tmp_path / "config.xml").write_text(cfg)
     os.environ["LS1HIP_MIRROR_SYNC_FINAL"] = "0"  # --final-checkpoint=0 and no plugins: nobody iterates after the run
+    res = {}
     try:
-        rows, log = _run(HIPB, "config.xml", str(tmp_path), 100)
+        for skin in ("default", "0"):
+            if skin != "default":
+                os.environ["LS1HIP_SKIN"] = skin
+            rows, log = _run(HIPB, "config.xml", str(tmp_path), 100)
+            speed = float(re.search(r"Simulation speed:\s*([0-9.eE+-]+)", log).group(1))
+            lists = re.search(r"neighbour lists (on|off): (\d+) builds for (\d+)", log)
+            res[skin] = (rows, speed)
+            print(f"[seam B] N={N} LS1HIP_SKIN={skin}: Simulation speed {speed:.4g} molecule-updates/s (reference driver, "
+                  f"device container; lists {lists.group(1)}, {lists.group(2)} builds / {lists.group(3)} evaluations)")
+            assert np.all(np.isfinite(rows)) and speed > 5e7
     finally:
         del os.environ["LS1HIP_MIRROR_SYNC_FINAL"]
-    speed = float(re.search(r"Simulation speed:\s*([0-9.eE+-]+)", log).group(1))
-    print(f"[seam B] N={N}: Simulation speed {speed:.4g} molecule-updates/s (reference driver, device container)")
-    assert np.all(np.isfinite(rows)) and speed > 5e7
+        os.environ.pop("LS1HIP_SKIN", None)
+    assert np.allclose(res["default"][0], res["0"][0], rtol=2e-5, atol=1e-12)  # same printed T / U_pot / p either way

@@ -186,3 +186,63 @@ def test_verlet_state_rules():
     a, b = _state(e), _state(e2)
     assert rel_max(a[2], b[2]) < 1e-10 and rel_max(a[3], b[3]) < 1e-9
     e.close(); e2.close()
+
+
+@pytest.mark.parametrize("skin", [0.3, 0.1])
+def test_verlet_nvt_run_matches_reference_trajectory(skin):
+    """10 thermostatted Leapfrog steps of the REAL reference (bcc1clj_3456_nvt10) through the list loop: with the
+    velocity-scaling thermostat the integrator passes stay separate kernels (kick, scale, kick+drift); the drift pass
+    advances the displacement bound, ls1hip_update decides between a halo refresh and a rebuild."""
+    name = "bcc1clj_3456_nvt10"
+    case = MAN[name]
+    g = read_golden(name)
+    ps = inp.read_inp(input_path(case["input"]))
+    st = sorted_phase_space(ps)
+    e = _engine(ps.components, case["rc"], ps.length, st["ids"], st["r"], st["v"], skin=skin)
+    e.set_thermostat(True, ps.temperature)
+    out = e.run(case["dt"], case["steps"])
+    assert e.get_option("verlet_steps") == case["steps"] and 1 <= e.get_option("verlet_builds") < case["steps"]
+    ids, r, v, F = _state(e)
+    rec = g["recs"]
+    L = ps.length
+    dr = r - rec["r"]
+    dr -= L * np.round(dr / L)
+    assert r.min() >= 0 and np.all(r < L)
+    assert np.max(np.abs(dr)) < 1e-9 * np.max(L)
+    assert rel_max(v, rec["v"]) < 1e-9
+    assert rel_max(F, rec["F"]) < 1e-8 and rel_componentwise(F, rec["F"]) < 1e-7
+    assert abs(out["upot"] - g["upot"]) / abs(g["upot"]) < 1e-9
+    e.close()
+
+
+@pytest.mark.parametrize("temp,steps", [(0.95, 60), (12.0, 30)])
+def test_verlet_piecewise_unfused_loop_over_many_rebuilds(temp, steps):
+    """The piecewise list-aware loop an adapter drives (ls1hip_update, ls1hip_forces_list with dt = 0, ls1hip_kick,
+    ls1hip_kick_drift — what LinkedCellsHip / LeapfrogHip call) == the per-step search loop, over several list
+    lifetimes; the rebuild decision comes from the bound the unfused drift kernel accumulates."""
+    dt = 0.002
+    L, ids, r, v = synth.bcc_box(20, temp=temp)
+    a = _engine(_lj(), 2.5, [L] * 3, ids, r, v, skin=None)
+    b = _engine(_lj(), 2.5, [L] * 3, ids, r, v, skin=0.25)
+    rebuilt = 0
+    for s in range(steps):
+        a.kick_drift(dt); a.rebin(); a.halo(); ua = a.forces(0, want_macro=True); ka = a.kick(0.5 * dt)
+        b.kick_drift(dt)
+        rebuilt += b.update()
+        ub = b.forces_list(0, 0.0, want_macro=True)
+        kb = b.kick(0.5 * dt)
+        assert abs(ua[0] - ub[0]) <= 1e-10 * abs(ua[0]) and abs(ua[1] - ub[1]) <= 1e-9 * abs(ua[1]), s
+        assert abs(ka[0] - kb[0]) <= 1e-10 * ka[0], s
+    vmax = np.sqrt((v * v).sum(1).max())
+    assert max(1, int(steps * dt * vmax * 0.5 / 0.125)) <= rebuilt <= steps // 2 + 1, rebuilt
+    assert b.get_option("verlet_builds") == rebuilt
+    sa, sb = _state(a), _state(b)
+    assert np.array_equal(sa[0], sb[0])
+    dr = sa[1] - sb[1]
+    dr -= L * np.round(dr / L)
+    assert np.max(np.abs(dr)) < 1e-10 * L
+    assert rel_max(sb[2], sa[2]) < 1e-10 and rel_max(sb[3], sa[3]) < 1e-9
+    # a second update without a drift in between only refreshes; lists off: update == rebin + halo
+    assert b.update() is False
+    assert a.update() is True
+    a.close(); b.close()

@@ -50,6 +50,8 @@ enum {
 #define LS1HIP_FK_AUTO 0      /* fastest parity-green kernel for the component set           */
 #define LS1HIP_FK_GENERIC 1   /* thread-per-molecule, global-memory neighbours (any density) */
 #define LS1HIP_FK_LDS_LIST 2  /* brick-tiled, LDS-staged, per-lane neighbour lists (1CLJ)    */
+#define LS1HIP_FK_MS_BRICK 3  /* multi-site, LDS-staged molecule pairs; bitwise == GENERIC (AUTO's choice for multi-site sets) */
+#define LS1HIP_FK_MS_SITES 4  /* multi-site, LDS tables + cached own sites + FMA bodies; 1e-12 of GENERIC; on request only   */
 
 /* ---- lifetime ------------------------------------------------------------------------------------------------- */
 

@@ -196,7 +196,7 @@ extern "C" int ls1hip_set_option(ls1hip_ctx* c, const char* name, long v) {
 	if (!c || !name) return LS1HIP_EINVAL;
 	std::string n(name);
 	if (n == "force_kernel") {
-		REQUIRE(c, v >= 0 && v <= 2, "force_kernel must be 0..2");
+		REQUIRE(c, v >= 0 && v <= 4, "force_kernel must be 0..4 (LS1HIP_FK_*)");
 		c->opt_force_kernel = v;
 	} else if (n == "cells_in_cutoff") {
 		REQUIRE(c, v == 1 || v == 2, "cells_in_cutoff must be 1 or 2");
@@ -933,6 +933,7 @@ static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
 	const bool first_pass = which == 0 || which == 1;
 	if (first_pass && c->opt_count_pairs) launch_clear_macro(c->d_cnt, c->stream);
 	bool done = false;
+	int family = LS1HIP_FK_LDS_LIST;
 	const double ncell = (double)c->g.box[0] * c->g.box[1] * c->g.box[2];
 	const double mean_per_cell = ncell > 0 ? (double)c->n_real / ncell : 0.;
 	if (fp.vl) {
@@ -942,11 +943,25 @@ static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
 		done = launch_force_lj(P, c->stream, &nblocks, c->d_partials, c->partials_cap, (int)c->opt_lj_split, mean_per_cell,
 							   &c->brick_lists);
 	} else if (!c->one_clj && c->opt_force_kernel != LS1HIP_FK_GENERIC && !c->opt_count_pairs && which != 3) {
-		done = launch_force_ms(P, c->opt_vi != 0, c->h_ct.has_rot != 0, c->stream, &nblocks, c->partials_cap, mean_per_cell,
-							   &c->brick_lists);
+		double vol = 1.;
+		for (int d = 0; d < 3; ++d) vol *= c->g.bmax[d] - c->g.bmin[d];
+		const double nbrs = vol > 0. ? (double)c->n_real / vol * 4.18879 * c->rc * c->rc * c->rc : 0.;
+		// AUTO = the molecule-pair brick kernel: at the 2-5 molecules per cell of the multi-site fixtures both kernels are bound
+		// by the per-brick staging / search chain, not by the pair bodies, and the site kernel (cheaper bodies, more phases)
+		// measured 10-20 % slower; it is there on request
+		if (c->opt_force_kernel == LS1HIP_FK_MS_SITES) {
+			done = launch_force_sites(P, c->h_ct, c->opt_vi != 0, c->stream, &nblocks, c->partials_cap, mean_per_cell, nbrs,
+									  &c->brick_lists);
+			if (done) family = LS1HIP_FK_MS_SITES;
+		}
+		if (!done) {
+			done = launch_force_ms(P, c->opt_vi != 0, c->h_ct.has_rot != 0, c->h_ct.ncomp == 1, c->stream, &nblocks, c->partials_cap,
+								   mean_per_cell, &c->brick_lists);
+			if (done) family = LS1HIP_FK_MS_BRICK;
+		}
 	}
 	if (!done && fuse) FAIL(c, LS1HIP_EINVAL, "fused force + integration needs the single-centre LJ fast path");
-	c->last_force_kernel = done ? (c->one_clj ? LS1HIP_FK_LDS_LIST : 3) : LS1HIP_FK_GENERIC;
+	c->last_force_kernel = done ? family : LS1HIP_FK_GENERIC;
 	if (!done) {
 		double vol = 1.;
 		for (int d = 0; d < 3; ++d) vol *= c->g.bmax[d] - c->g.bmin[d];

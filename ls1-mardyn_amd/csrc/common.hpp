@@ -312,8 +312,11 @@ int verlet_region_capacity();  // molecules of a brick's region the list kernels
 int verlet_region_cells();
 void verlet_brick_shape(int shape[3]);  // cells per brick edge of the list kernels
 // brick-tiled multi-site kernel (kernels_force_ms.hip); returns false if it cannot handle the configuration
-bool launch_force_ms(const ForceParams& p, bool with_vi, bool has_rot, hipStream_t s, uint32_t* nblocks, size_t partials_cap,
-					 double mean_per_cell, BrickLists* bl);
+bool launch_force_ms(const ForceParams& p, bool with_vi, bool has_rot, bool one_component, hipStream_t s, uint32_t* nblocks,
+					 size_t partials_cap, double mean_per_cell, BrickLists* bl);
+// site kernel (kernels_force_sites.hip): LDS-resident tables, cached own sites, LPM lanes per molecule, launch-time brick shape
+bool launch_force_sites(const ForceParams& p, const CompTable& hct, bool with_vi, hipStream_t s, uint32_t* nblocks,
+						size_t partials_cap, double mean_per_cell, double mean_neighbours, BrickLists* bl);
 // kin_in_slot1: the partials' slot 1 carries sum m v^2 of a fused force + integration pass (goes to cnt->kin[0], not to
 // the macroscopic sums); log (may be null): the step-log row {U_pot, virial, sum m v^2, sum I w^2, N, rotDOF} to refresh
 struct ReduceMode {

@@ -15,6 +15,8 @@
 //   * list overflow and shells larger than the staging area fall back to direct evaluation (same arithmetic).
 // Against k_force_generic (neighbours fetched by every lane from global memory: 27 dependent, uncoalesced cell walks per
 // molecule) positions arrive coalesced once per brick and the search runs out of LDS.
+#include <type_traits>
+
 #include "common.hpp"
 #include "brick.hpp"
 
@@ -38,8 +40,10 @@ __device__ __forceinline__ void ms_block_reduce4(double v0, double v1, double v2
 	}
 }
 
-template <int BX, int BY, int BZ, int CAPJ, int CAPL, bool WITH_VI, bool HAS_ROT>
-__global__ void __launch_bounds__(MTPB) k_force_ms_brick(ForceParams P, int nbx, int nby, int nbz) {
+template <int BX, int BY, int BZ, int CAPJ, int CAPL, bool WITH_VI, bool HAS_ROT, bool ONEC>
+__global__ void __launch_bounds__(MTPB) k_force_ms_brick(ForceParams P, const CompTable* __restrict__ ctab, int nbx, int nby, int nbz) {
+	// (the component table as its own noalias argument: its loads are then known not to be clobbered by the force stores, and
+	// with uniform indices become scalar loads)
 	constexpr int HW = 1, NT = MTPB;
 	constexpr int RX = BX + 2 * HW, RY = BY + 2 * HW, RZ = BZ + 2 * HW;
 	constexpr int NRC = RX * RY * RZ;
@@ -111,8 +115,8 @@ __global__ void __launch_bounds__(MTPB) k_force_ms_brick(ForceParams P, int nbx,
 	}
 	__syncthreads();
 
-	const double rc2 = P.ct->rc2, rclj2 = P.ct->rclj2;
-	const int ncomp = P.ct->ncomp;
+	const double rc2 = ctab->rc2, rclj2 = ctab->rclj2;
+	const int ncomp = ctab->ncomp;
 	// owned enumeration index -> (region cell, rank in cell)
 	auto locate = [&](uint32_t it, int& lo_out) {
 		int lo = 0, hi = NBC;
@@ -192,13 +196,13 @@ __global__ void __launch_bounds__(MTPB) k_force_ms_brick(ForceParams P, int nbx,
 		acc.u6 = acc.uX = acc.rf = acc.vir = 0.;
 		if (staged) {
 			const V3 ri = {sx[ii], sy[ii], sz[ii]};
-			const int ci = scid[ii];
+			const int ci = ONEC ? 0 : (int)scid[ii];  // one component: every table index is a compile-time constant -> scalar loads
 			const Rot Ri = HAS_ROT ? rot_of(sq0[ii], sq1[ii], sq2[ii], sq3[ii]) : rot_of(1., 0., 0., 0.);
 			auto pair = [&](uint32_t j) {  // candidate j (LDS index): exact test done by the caller
 				const V3 rj = {sx[j], sy[j], sz[j]};
 				const V3 drm = ri - rj;
 				const Rot Rj = HAS_ROT ? rot_of(sq0[j], sq1[j], sq2[j], sq3[j]) : rot_of(1., 0., 0., 0.);
-				mol_pair<WITH_VI>(*P.ct, ci, ri, Ri, (int)scid[j], rj, Rj, drm, dot(drm, drm) < rclj2, 0.5, acc);
+				mol_pair<WITH_VI>(*ctab, ci, ri, Ri, ONEC ? 0 : (int)scid[j], rj, Rj, drm, dot(drm, drm) < rclj2, 0.5, acc);
 			};
 			// Phase 1 / phase 2 in windows of CAPL hits (one window unless the neighbourhood is very dense): the walk over
 			// the 9 neighbour rows appends the hits number [done, done + CAPL) to the per-lane list, the molecule-pair body
@@ -228,7 +232,7 @@ __global__ void __launch_bounds__(MTPB) k_force_ms_brick(ForceParams P, int nbx,
 		} else {
 			// shell does not fit the staging area: same walk straight from global memory
 			const V3 ri = {P.x[gi], P.y[gi], P.z[gi]};
-			const int ci = P.cid[gi];
+			const int ci = ONEC ? 0 : P.cid[gi];
 			Rot Ri = rot_of(1., 0., 0., 0.);
 			if (HAS_ROT) {
 				const double w = P.q0[gi], x = P.q1[gi], y = P.q2[gi], z = P.q3[gi];
@@ -251,7 +255,7 @@ __global__ void __launch_bounds__(MTPB) k_force_ms_brick(ForceParams P, int nbx,
 							const double inv = 1. / sqrt(w * w + x * x + y * y + z * z);
 							Rj = rot_of(w * inv, x * inv, y * inv, z * inv);
 						}
-						mol_pair<WITH_VI>(*P.ct, ci, ri, Ri, P.cid[j], rj, Rj, drm, dd < rclj2, 0.5, acc);
+						mol_pair<WITH_VI>(*ctab, ci, ri, Ri, ONEC ? 0 : P.cid[j], rj, Rj, drm, dd < rclj2, 0.5, acc);
 					}
 				}
 			}
@@ -278,7 +282,7 @@ __global__ void __launch_bounds__(MTPB) k_force_ms_brick(ForceParams P, int nbx,
 }
 
 template <int BX, int BY, int BZ, int CAPJ_ROT, int CAPJ_NOROT, int CAPL>
-static bool launch_ms(ForceParams p, BrickLists* bl, bool with_vi, bool has_rot, hipStream_t s, uint32_t* nblocks,
+static bool launch_ms(ForceParams p, BrickLists* bl, bool with_vi, bool has_rot, bool onec, hipStream_t s, uint32_t* nblocks,
 					  size_t partials_cap) {
 	const Grid& g = p.g;
 	const int nbx = (g.box[0] + BX - 1) / BX, nby = (g.box[1] + BY - 1) / BY, nbz = (g.box[2] + BZ - 1) / BZ;
@@ -288,12 +292,20 @@ static bool launch_ms(ForceParams p, BrickLists* bl, bool with_vi, bool has_rot,
 	*nblocks = (uint32_t)nb;
 	if (nb == 0) return true;
 	const dim3 grid((uint32_t)nb), block(MTPB);
+	auto go = [&](auto vi, auto rot, auto one) {
+		constexpr bool VI = decltype(vi)::value, ROT = decltype(rot)::value, ONE = decltype(one)::value;
+		hipLaunchKernelGGL((k_force_ms_brick<BX, BY, BZ, ROT ? CAPJ_ROT : CAPJ_NOROT, CAPL, VI, ROT, ONE>), grid, block, 0, s, p, p.ct, nbx, nby, nbz);
+	};
+	auto pick = [&](auto vi, auto rot) {
+		if (onec) go(vi, rot, std::true_type{});
+		else go(vi, rot, std::false_type{});
+	};
 	if (has_rot) {
-		if (with_vi) hipLaunchKernelGGL((k_force_ms_brick<BX, BY, BZ, CAPJ_ROT, CAPL, true, true>), grid, block, 0, s, p, nbx, nby, nbz);
-		else hipLaunchKernelGGL((k_force_ms_brick<BX, BY, BZ, CAPJ_ROT, CAPL, false, true>), grid, block, 0, s, p, nbx, nby, nbz);
+		if (with_vi) pick(std::true_type{}, std::true_type{});
+		else pick(std::false_type{}, std::true_type{});
 	} else {
-		if (with_vi) hipLaunchKernelGGL((k_force_ms_brick<BX, BY, BZ, CAPJ_NOROT, CAPL, true, false>), grid, block, 0, s, p, nbx, nby, nbz);
-		else hipLaunchKernelGGL((k_force_ms_brick<BX, BY, BZ, CAPJ_NOROT, CAPL, false, false>), grid, block, 0, s, p, nbx, nby, nbz);
+		if (with_vi) pick(std::true_type{}, std::false_type{});
+		else pick(std::false_type{}, std::false_type{});
 	}
 	return true;
 }
@@ -306,16 +318,16 @@ static bool launch_ms(ForceParams p, BrickLists* bl, bool with_vi, bool has_rot,
 // (measured: ethane at 2 molecules per cell in 4x2x2-cell bricks = 32 owned molecules per workgroup ran no faster than
 // the generic kernel).  So the brick shape follows the mean cell occupancy: the largest shape whose shell still fits the
 // staging area with 8 % headroom.  Returns false (-> k_force_generic) when even the smallest brick would overflow.
-bool launch_force_ms(const ForceParams& p, bool with_vi, bool has_rot, hipStream_t s, uint32_t* nblocks, size_t partials_cap,
-					 double mean_per_cell, BrickLists* bl) {
+bool launch_force_ms(const ForceParams& p, bool with_vi, bool has_rot, bool onec, hipStream_t s, uint32_t* nblocks,
+					 size_t partials_cap, double mean_per_cell, BrickLists* bl) {
 	if (p.g.hw != 1 || p.ct == nullptr) return false;
 	const double m = mean_per_cell * 1.08;
 	const double cs = has_rot ? 1050. : 2400., cd = has_rot ? 770. : 1730.;
-	if (m * (10 * 6 * 6) <= cs) return launch_ms<8, 4, 4, 1050, 2400, 31>(p, bl, with_vi, has_rot, s, nblocks, partials_cap);
-	if (m * (6 * 6 * 6) <= cs) return launch_ms<4, 4, 4, 1050, 2400, 31>(p, bl, with_vi, has_rot, s, nblocks, partials_cap);
-	if (m * (6 * 6 * 4) <= cd) return launch_ms<4, 4, 2, 770, 1730, 63>(p, bl, with_vi, has_rot, s, nblocks, partials_cap);
-	if (m * (6 * 4 * 4) <= cd) return launch_ms<4, 2, 2, 770, 1730, 63>(p, bl, with_vi, has_rot, s, nblocks, partials_cap);
-	if (m * (4 * 4 * 4) <= cd) return launch_ms<2, 2, 2, 770, 1730, 63>(p, bl, with_vi, has_rot, s, nblocks, partials_cap);
+	if (m * (10 * 6 * 6) <= cs) return launch_ms<8, 4, 4, 1050, 2400, 31>(p, bl, with_vi, has_rot, onec, s, nblocks, partials_cap);
+	if (m * (6 * 6 * 6) <= cs) return launch_ms<4, 4, 4, 1050, 2400, 31>(p, bl, with_vi, has_rot, onec, s, nblocks, partials_cap);
+	if (m * (6 * 6 * 4) <= cd) return launch_ms<4, 4, 2, 770, 1730, 63>(p, bl, with_vi, has_rot, onec, s, nblocks, partials_cap);
+	if (m * (6 * 4 * 4) <= cd) return launch_ms<4, 2, 2, 770, 1730, 63>(p, bl, with_vi, has_rot, onec, s, nblocks, partials_cap);
+	if (m * (4 * 4 * 4) <= cd) return launch_ms<2, 2, 2, 770, 1730, 63>(p, bl, with_vi, has_rot, onec, s, nblocks, partials_cap);
 	return false;
 }
 

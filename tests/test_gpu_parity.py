@@ -519,12 +519,36 @@ def test_multisite_brick_kernel_is_bitwise_the_generic_kernel(name):
     ps = inp.read_inp(input_path(case["input"]))
     st = sorted_phase_space(ps)
     gen = run_forces(ps, st, case["rc"], bool(case["periodic"]), kernel=capi.FK_GENERIC)
-    brk = run_forces(ps, st, case["rc"], bool(case["periodic"]), kernel=capi.FK_AUTO)
+    brk = run_forces(ps, st, case["rc"], bool(case["periodic"]), kernel=capi.FK_MS_BRICK)
     assert gen["kernel_family"] == 1 and brk["kernel_family"] == 3  # generic vs multi-site brick kernel, really
     for k in ("F", "M", "Vi"):  # candidates are visited in the generic kernel's order: bitwise
         assert np.array_equal(gen[k], brk[k]), k
     assert abs(gen["upot"] - brk["upot"]) <= 1e-13 * max(abs(gen["upot"]), 1e-300) + 1e-300
     assert abs(gen["virial"] - brk["virial"]) <= 1e-13 * max(abs(gen["virial"]), 1e-300) + 1e-300
+
+
+def _close_to_generic(gen, out, tol=1e-12, what=None):
+    """site kernel vs generic kernel: different summation order, FMA, Newton-refined reciprocals -> 1e-12 of the largest
+    component (forces, torques, per-molecule virials) and of the sums"""
+    for k in ("F", "M", "Vi"):
+        if k in gen and gen[k] is not None and np.max(np.abs(gen[k])) > 0:
+            assert rel_max(out[k], gen[k]) < tol, (k, what)
+    assert abs(gen["upot"] - out["upot"]) <= tol * max(abs(gen["upot"]), 1e-300) + 1e-300, what
+    assert abs(gen["virial"] - out["virial"]) <= tol * max(abs(gen["virial"]), 1e-300) + 1e-300, what
+
+
+@pytest.mark.parametrize("name", MULTISITE_CASES)
+def test_multisite_site_kernel_matches_the_generic_kernel(name):
+    """k_force_sites (LDS tables, cached own sites, FMA, v_rcp / v_rsq + Newton; LS1HIP_FK_MS_SITES, on request) against
+    k_force_generic on the reference's fixtures: 1e-12; FK_AUTO runs the molecule-pair brick kernel."""
+    case = MAN[name]
+    ps = inp.read_inp(input_path(case["input"]))
+    st = sorted_phase_space(ps)
+    gen = run_forces(ps, st, case["rc"], bool(case["periodic"]), kernel=capi.FK_GENERIC)
+    sit = run_forces(ps, st, case["rc"], bool(case["periodic"]), kernel=capi.FK_MS_SITES)
+    assert gen["kernel_family"] == 1 and sit["kernel_family"] == capi.FK_MS_SITES
+    _close_to_generic(gen, sit, what=name)
+    assert run_forces(ps, st, case["rc"], bool(case["periodic"]), kernel=capi.FK_AUTO)["kernel_family"] == capi.FK_MS_BRICK
 
 
 def test_multisite_brick_kernel_fallbacks_and_split():
@@ -543,19 +567,14 @@ def test_multisite_brick_kernel_fallbacks_and_split():
                         r, np.zeros((N, 3)), q, np.zeros((N, 3)))
     st = sorted_phase_space(ps)
     gen = run_forces(ps, st, rc, True, kernel=capi.FK_GENERIC)
-    brk = run_forces(ps, st, rc, True, kernel=capi.FK_AUTO)
+    brk = run_forces(ps, st, rc, True, kernel=capi.FK_MS_BRICK)
     for k in ("F", "M", "Vi"):
         assert np.array_equal(gen[k], brk[k]), k
-    cont = brk["container"]
-    dom = mirror.Domain(ps.length)
-    cp = mirror.VectorizedCellProcessor(dom, rc, rc)
-    cont.traversePartialInnermostCells(cp, 0, 1)
-    cont.traverseNonInnermostCells(cp)
-    mol = cont.molecules()
-    frc = cont.forces()
-    o = np.argsort(mol["ids"])
-    assert np.array_equal(frc["F"][o], brk["F"]) and np.array_equal(frc["M"][o], brk["M"])
-    assert abs(dom.getLocalUpot() - brk["upot"]) <= 1e-13 * abs(brk["upot"])
+    sit = run_forces(ps, st, rc, True, kernel=capi.FK_MS_SITES)
+    assert sit["kernel_family"] == capi.FK_MS_SITES
+    _close_to_generic(gen, sit, what="liquid-like ethane")
+    for which, res in (("brick", brk), ("sites", sit)):
+        _inner_boundary_split_equals_full(ps, rc, res)
     # (b) dense cluster: 1500 molecules inside one cutoff sphere (+ 300 spread out)
     N = 1800
     L = 6 * rc
@@ -565,10 +584,26 @@ def test_multisite_brick_kernel_fallbacks_and_split():
                         r, np.zeros((N, 3)), q, np.zeros((N, 3)))
     st = sorted_phase_space(ps)
     gen = run_forces(ps, st, rc, True, kernel=capi.FK_GENERIC, vi=False)
-    brk = run_forces(ps, st, rc, True, kernel=capi.FK_AUTO, vi=False)
+    brk = run_forces(ps, st, rc, True, kernel=capi.FK_MS_BRICK, vi=False)
     for k in ("F", "M"):
         assert np.array_equal(gen[k], brk[k]), k
     assert abs(gen["upot"] - brk["upot"]) <= 1e-12 * abs(gen["upot"])
+    sit = run_forces(ps, st, rc, True, kernel=capi.FK_MS_SITES, vi=False)
+    assert sit["kernel_family"] == capi.FK_MS_SITES  # bricks beyond the staging area evaluate from global memory
+    _close_to_generic(gen, sit, tol=1e-11, what="dense cluster")
+
+
+def _inner_boundary_split_equals_full(ps, rc, res):
+    cont = res["container"]
+    dom = mirror.Domain(ps.length)
+    cp = mirror.VectorizedCellProcessor(dom, rc, rc)
+    cont.traversePartialInnermostCells(cp, 0, 1)
+    cont.traverseNonInnermostCells(cp)
+    mol = cont.molecules()
+    frc = cont.forces()
+    o = np.argsort(mol["ids"])
+    assert np.array_equal(frc["F"][o], res["F"]) and np.array_equal(frc["M"][o], res["M"])
+    assert abs(dom.getLocalUpot() - res["upot"]) <= 1e-13 * abs(res["upot"])
 
 
 @pytest.mark.parametrize("name", [k for k in FORCE_CASES])
@@ -653,13 +688,18 @@ def test_multisite_brick_random_boxes(seed):
     ps = inp.PhaseSpace(comps, L, np.arange(1, N + 1, dtype=np.uint64), cid, r, np.zeros((N, 3)), q, np.zeros((N, 3)))
     st = sorted_phase_space(ps)
     gen = run_forces(ps, st, rc, True, kernel=capi.FK_GENERIC)
-    brk = run_forces(ps, st, rc, True, kernel=capi.FK_AUTO)
+    brk = run_forces(ps, st, rc, True, kernel=capi.FK_MS_BRICK)
     assert gen["kernel_family"] == 1
     assert brk["kernel_family"] == (3 if per_cell * 64 * 1.08 <= 770 else brk["kernel_family"])
     for k in ("F", "M", "Vi"):
         assert np.array_equal(gen[k], brk[k]), (k, ncell.tolist(), per_cell)
     assert abs(gen["upot"] - brk["upot"]) <= 1e-12 * abs(gen["upot"]) + 1e-300
     assert abs(gen["virial"] - brk["virial"]) <= 1e-12 * abs(gen["virial"]) + 1e-300
+    # the site kernel (every brick shape / lanes-per-molecule choice its host heuristic makes over this density range)
+    sit = run_forces(ps, st, rc, True, kernel=capi.FK_MS_SITES)
+    if per_cell < 6:
+        assert sit["kernel_family"] == capi.FK_MS_SITES, per_cell
+    _close_to_generic(gen, sit, tol=1e-11, what=(ncell.tolist(), per_cell, sit["kernel_family"]))
 
 
 def test_dense_multisite_liquid_four_lanes_per_molecule():

@@ -20,3 +20,5 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
 	echo "pass $name done"
 done
 python3 tools/pmc_summarize.py "$OUT" $*
+# keep the summaries, drop the raw per-dispatch outputs (gpurun copies back at most 64 MiB)
+find "$OUT" -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +

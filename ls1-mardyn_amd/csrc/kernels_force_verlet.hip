@@ -73,11 +73,11 @@ void verlet_geometry(const Grid& g, long* nbricks, size_t* words_per_brick, size
 	*tiles_per_brick = VMAXT;
 }
 
+// 1 / d: v_rcp_f64 (measured on gfx950: 4.6e-8 relative, tools/probes/rcp_probe.hip) + ONE Newton step = 2.2e-15 relative;
+// the second step (1.1e-16) costs two of the ~27 VALU instructions of a pair and buys nothing at the 1e-10 parity bar
 __device__ __forceinline__ double v_rcp(double d) {
-	double x = __builtin_amdgcn_rcp(d);
-	double e = fma(-d, x, 1.0);
-	x = fma(x, e, x);
-	e = fma(-d, x, 1.0);
+	const double x = __builtin_amdgcn_rcp(d);
+	const double e = fma(-d, x, 1.0);
 	return fma(x, e, x);
 }
 
@@ -94,18 +94,26 @@ __device__ __forceinline__ void v_pair(double xi, double yi, double zi, double x
 	const double dx = xi - xj, dy = yi - yj, dz = zi - zj;
 	const double r2 = fma(dz, dz, fma(dy, dy, dx * dx));
 	const bool in = r2 < rc2;
-	const double inv = v_rcp(in ? r2 : 1.0e300);
+	// out of range: replace only the HIGH dword by that of 1e300 (one v_cndmask instead of two; any low dword will do)
+	const double inv = v_rcp(__hiloint2double(in ? __double2hiint(r2) : 0x7E37E43C, __double2loint(r2)));
 	const double lj2 = sig2 * inv;
 	const double lj6 = lj2 * lj2 * lj2;
-	const double lj12 = lj6 * lj6;
-	const double lj12m6 = lj12 - lj6;
-	const double fac = eps24 * inv * (lj12 + lj12m6);
+	const double lj12m6 = fma(lj6, lj6, -lj6);              // lj12 - lj6
+	const double fac = inv * fma(lj6, lj6, lj12m6);          // (lj12 + lj12m6) / r2  // (24 eps applied once per molecule: v_pair_scale)
 	a.fx = fma(fac, dx, a.fx);
 	a.fy = fma(fac, dy, a.fy);
 	a.fz = fma(fac, dz, a.fz);
 	a.slj += lj12m6;
 	if (COUNT) a.nin += in ? 1u : 0u;
 	a.vir = fma(fac, r2, a.vir);
+}
+
+// the factor 24 eps common to every pair of the molecule
+__device__ __forceinline__ void v_pair_scale(VAcc& a, double eps24) {
+	a.fx *= eps24;
+	a.fy *= eps24;
+	a.fz *= eps24;
+	a.vir *= eps24;
 }
 
 __device__ __forceinline__ double v_wave_sum(double v) {
@@ -250,6 +258,7 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 			}
 		}
 		if (active) {
+			v_pair_scale(acc, eps24);
 			const double fx = acc.fx, fy = acc.fy, fz = acc.fz;
 			if (!P.fuse) {
 				P.Fx[gi] = fx;

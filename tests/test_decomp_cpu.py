@@ -146,3 +146,28 @@ def test_engine_error_on_one_rank_fails_every_rank_without_hanging(where):
         assert res.returncode != 0
         assert res.stderr.count("DecompositionError") >= 2, res.stderr[-3000:]
         assert "injected engine failure" in res.stderr
+
+
+@pytest.mark.parametrize("world,loopback", [(1, 0), (1, 1), (2, 0), (4, 0), (8, 0), (8, 1), (12, 0), (27, 0)])
+def test_cpp_rank_grid_matches_the_python_decomposition(world, loopback):
+    """CartDecomp of host/DomainDecompRccl.hpp (the C++ / RCCL decomposed loop) == decomp.CartesianDecomposition: grid,
+    coordinates, bounding boxes (bitwise), the 27-entry neighbour tables incl. loopback aliases, peer sets."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "hostcpp", "decomp_rccl_main")
+    if not os.path.exists(exe):
+        pytest.skip("tests/hostcpp/decomp_rccl_main not built")
+    out = subprocess.run([exe, "--geometry", str(world), str(loopback)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == world
+    L = np.array([10., 12., 14.])
+    for ln in lines:
+        left, right = ln.split("|")
+        t = left.split()
+        r = int(t[0])
+        dc = decomp.CartesianDecomposition(world, r, L, loopback=bool(loopback))
+        assert tuple(int(x) for x in t[1:4]) == dc.grid and tuple(int(x) for x in t[4:7]) == dc.coords
+        lo, hi = dc.bounding_box()
+        assert np.array_equal(np.array([float(x) for x in t[7:10]]), lo) and np.array_equal(np.array([float(x) for x in t[10:13]]), hi)
+        assert [int(x) for x in t[13:40]] == [int(x) for x in dc.neighbor_table()]
+        assert [int(x) for x in right.split()] == dc.peers()

@@ -476,19 +476,20 @@ __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int n
 			const uint32_t ii = cstart[rcell] + (it - bstart[lo]);
 			const int rowbase = (cz * RY + cy) * RX + cx;
 			const f32x2 xi = {fx[ii], fx[ii]}, yi = {fy[ii], fy[ii]}, zi = {fz[ii], fz[ii]};
-			const uint32_t wb = (uint32_t)tid * 2u;  // byte offset of this lane inside a window row (rows of NT * 2 = 1024 B)
+			const uint32_t wb = (uint32_t)tid * 2u;  // byte offset of this lane inside a window row (rows of ROWB = NT * 2 bytes)
+			constexpr uint32_t ROWB = (uint32_t)NT * 2u;
 			char* const winb = reinterpret_cast<char*>(win);
 			// one candidate: unconditional store of its offset at slot cnt & 7, cnt advances on a hit (a miss is overwritten)
 			auto put = [&](uint32_t j, bool hit) {
-				*reinterpret_cast<uint16_t*>(winb + (((cnt << 10) & 0x1c00u) | wb)) = (uint16_t)(j * 8u);
+				*reinterpret_cast<uint16_t*>(winb + ((cnt & 7u) * ROWB + wb)) = (uint16_t)(j * 8u);
 				cnt += hit ? 1u : 0u;
 			};
 			auto flush = [&](uint32_t before) {
 				if ((cnt >> 2) != (before >> 2)) {  // a word of four entries is complete
 					const uint32_t w = before >> 2;
-					const char* const s0 = winb + ((w & 1u) * 4096u + wb);
-					const uint64_t e0 = *reinterpret_cast<const uint16_t*>(s0), e1 = *reinterpret_cast<const uint16_t*>(s0 + 1024),
-								   e2 = *reinterpret_cast<const uint16_t*>(s0 + 2048), e3 = *reinterpret_cast<const uint16_t*>(s0 + 3072);
+					const char* const s0 = winb + ((w & 1u) * (4u * ROWB) + wb);
+					const uint64_t e0 = *reinterpret_cast<const uint16_t*>(s0), e1 = *reinterpret_cast<const uint16_t*>(s0 + ROWB),
+								   e2 = *reinterpret_cast<const uint16_t*>(s0 + 2 * ROWB), e3 = *reinterpret_cast<const uint16_t*>(s0 + 3 * ROWB);
 					if (w < (uint32_t)VMAXW) wp[(size_t)w * 64] = e0 | (e1 << 16) | (e2 << 32) | (e3 << 48);
 				}
 			};
@@ -531,10 +532,10 @@ __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int n
 			// the incomplete last word, padded with the dummy entry
 			const uint32_t w = cnt >> 2, rem = cnt & 3u;
 			if (rem && w < (uint32_t)VMAXW) {
-				const char* const s0 = winb + ((w & 1u) * 4096u + wb);
+				const char* const s0 = winb + ((w & 1u) * (4u * ROWB) + wb);
 				uint64_t word = dummy;
 				for (uint32_t u = 0; u < rem; ++u) {
-					const uint64_t e = *reinterpret_cast<const uint16_t*>(s0 + u * 1024u);
+					const uint64_t e = *reinterpret_cast<const uint16_t*>(s0 + u * ROWB);
 					word = (word & ~(0xffffull << (16 * u))) | (e << (16 * u));
 				}
 				wp[(size_t)w * 64] = word;

@@ -104,7 +104,7 @@ static void free_mol(ls1hip_ctx* c) {
 	dfree(c->d_exp_halo_src); dfree(c->d_imp_slot); dfree(c->d_s2s); dfree(c->d_exp_refresh);
 	c->vl_ready = false;
 	dfree(c->alt_x); dfree(c->alt_y); dfree(c->alt_z);
-	dfree(c->d_vl_words); dfree(c->d_vl_nw);
+	dfree(c->d_vl_words); dfree(c->d_vl_nw); dfree(c->d_vl_rec); dfree(c->d_vl_ii); dfree(c->d_vl_gi);
 	c->vl_words_cap = c->vl_tiles_cap = 0;
 	c->pos_x = c->pos_y = c->pos_z = nullptr;
 	dfree(c->d_key); dfree(c->d_rank); dfree(c->d_perm); dfree(c->d_ckey); dfree(c->d_idk);
@@ -900,6 +900,9 @@ static void fill_force_params(ls1hip_ctx* c, ForceParams& P, int which) {
 	P.vl_rc2 = c->rc_list * c->rc_list;
 	P.vl_words = c->d_vl_words;
 	P.vl_nw = c->d_vl_nw;
+	P.vl_rec = c->d_vl_rec;
+	P.vl_ii = c->d_vl_ii;
+	P.vl_gi = c->d_vl_gi;
 }
 
 static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
@@ -1299,9 +1302,15 @@ static int ensure_verlet_buffers(ls1hip_ctx* c) {
 	if (words > c->vl_words_cap || tiles > c->vl_tiles_cap) {
 		dfree(c->d_vl_words);
 		dfree(c->d_vl_nw);
+		dfree(c->d_vl_rec);
+		dfree(c->d_vl_ii);
+		dfree(c->d_vl_gi);
 		c->vl_words_cap = c->vl_tiles_cap = 0;
 		int rc;
-		if ((rc = dalloc(c, &c->d_vl_words, words)) || (rc = dalloc(c, &c->d_vl_nw, tiles))) return rc;
+		if ((rc = dalloc(c, &c->d_vl_words, words)) || (rc = dalloc(c, &c->d_vl_nw, tiles)) ||
+			(rc = dalloc(c, &c->d_vl_rec, (size_t)nbricks * verlet_record_words())) || (rc = dalloc(c, &c->d_vl_ii, tiles * 64)) ||
+			(rc = dalloc(c, &c->d_vl_gi, tiles * 64)))
+			return rc;
 		c->vl_words_cap = words;
 		c->vl_tiles_cap = tiles;
 	}

@@ -89,6 +89,9 @@ struct ForceParams {
 	double vl_rc2;       // (rc + skin)^2: list cutoff
 	uint64_t* vl_words;  // [brick][tile][word][64 lanes]: 4 u16 LDS byte offsets per word
 	uint8_t* vl_nw;      // [brick][tile]: words per lane in use (wave maximum), 0xff = overflow -> direct evaluation
+	uint32_t* vl_rec;    // [brick][verlet_record_words()]: region cell table + flags, written by the build
+	uint16_t* vl_ii;     // [brick][tiles * 64]: LDS slot of every owned molecule
+	uint32_t* vl_gi;     // [brick][tiles * 64]: global index of every owned molecule
 };
 
 // inner / boundary brick lists of the LJ brick kernels for the current grid and brick shape (kernels_force_lj.hip)
@@ -179,6 +182,9 @@ struct ls1hip_ctx {
 	double rc_list = 0.;  // rc + skin: cutoff of the cell grid, the halo shell and the lists
 	uint64_t* d_vl_words = nullptr;
 	uint8_t* d_vl_nw = nullptr;
+	uint32_t* d_vl_rec = nullptr;
+	uint16_t* d_vl_ii = nullptr;
+	uint32_t* d_vl_gi = nullptr;
 	size_t vl_words_cap = 0, vl_tiles_cap = 0;
 	double *alt_x = nullptr, *alt_y = nullptr, *alt_z = nullptr;  // second position buffer (owned + halo segment)
 	bool vl_valid = false;       // the lists match the current binning and the displacement bound is tracked on the device
@@ -310,7 +316,8 @@ bool launch_force_verlet(const ForceParams& p, hipStream_t s, uint32_t* nblocks,
 void verlet_geometry(const Grid& g, long* nbricks, size_t* words_per_brick, size_t* tiles_per_brick);
 int verlet_region_capacity();  // molecules of a brick's region the list kernels can stage in LDS
 int verlet_region_cells();
-void verlet_brick_shape(int shape[3]);  // cells per brick edge of the list kernels
+void verlet_brick_shape(int shape[3]);
+int verlet_record_words();  // cells per brick edge of the list kernels
 // brick-tiled multi-site kernel (kernels_force_ms.hip); returns false if it cannot handle the configuration
 bool launch_force_ms(const ForceParams& p, bool with_vi, bool has_rot, bool one_component, hipStream_t s, uint32_t* nblocks,
 					 size_t partials_cap, double mean_per_cell, BrickLists* bl);

@@ -54,6 +54,8 @@ constexpr int VCAPJ = 2816;            // staged molecules per brick region (67.
 constexpr int VCAPS = VCAPJ + 8;       // +8: the dummy slot and the overrun of unrolled row reads
 constexpr int VMAXT = 10;    // tiles per brick with stored lists (640 owned molecules); further tiles: direct evaluation
 constexpr int VMAXW = 24;    // words per lane = 96 list entries
+// per-brick record written by the build: cstart[VNRC + 1], gbeg[VNRC], owned count, flags (bit 0: every tile listed, staged)
+constexpr int VREC_GBEG = VNRC + 1, VREC_NI = 2 * VNRC + 1, VREC_FLAGS = 2 * VNRC + 2, VREC = 2 * VNRC + 8;
 constexpr double VFAR = 1.0e30;  // dummy position: r^2 ~ 1e60 fails every cutoff test, all LJ terms underflow to 0
 static_assert(VNRC <= VNT * 4, "region too large for the block scan");
 static_assert(2 * VCAPS * 8 < 65536, "y / z are addressed as constant offsets from the x entry");
@@ -72,6 +74,7 @@ void verlet_geometry(const Grid& g, long* nbricks, size_t* words_per_brick, size
 	*words_per_brick = (size_t)VMAXT * VMAXW * 64;
 	*tiles_per_brick = VMAXT;
 }
+int verlet_record_words() { return VREC; }
 
 // 1 / d: v_rcp_f64 (measured on gfx950: 4.6e-8 relative, tools/probes/rcp_probe.hip) + ONE Newton step = 2.2e-15 relative;
 // the second step (1.1e-16) costs two of the ~27 VALU instructions of a pair and buys nothing at the 1e-10 parity bar
@@ -157,7 +160,9 @@ __device__ __forceinline__ ListHead load_list_head(const ForceParams& P, int bri
 // Forces of the owned molecules of ONE brick from the stored lists (positions staged in sx / sy / sz, table in T).
 template <bool SHIFT>
 __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTab& T, const double* sx, const double* sy,
-											 const double* sz, int brick_id, bool staged, const ListHead& head, Totals& tot) {
+											 const double* sz, int brick_id, bool staged, const ListHead& head, Totals& tot,
+											 const uint16_t* fast_ii = nullptr, const uint32_t* fast_gi = nullptr, uint32_t ii0 = 0,
+											 uint32_t gi0 = 0) {
 	constexpr int NT = VNT, NW = VNW, RX = VRX, RY = VRY, BX = VBX, BY = VBY, NBC = VNBC, CAPS = VCAPS;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const uint32_t total = T.cstart[VNRC], n_i = T.bstart[NBC];
@@ -170,7 +175,10 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 		const size_t tile_g = (size_t)brick_id * VMAXT + tile;
 		uint32_t ii = total, gi = 0;
 		int rowbase = 0;
-		if (active) {
+		if (active && fast_ii) {  // regular brick: own LDS slot and global index as recorded by the build (no table search)
+			ii = pass == 0 ? ii0 : (uint32_t)fast_ii[it];  // first pass: loaded by the caller ahead of the staging
+			gi = pass == 0 ? gi0 : fast_gi[it];
+		} else if (active) {
 			int lo = 0, hi = NBC;
 			while (hi - lo > 1) {
 				const int mid = (lo + hi) >> 1;
@@ -427,13 +435,25 @@ __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int n
 	__shared__ uint32_t bstart[NBC + 1];
 	__shared__ uint32_t wsum[VNW];
 	__shared__ uint16_t win[8 * NT];  // per-lane window of two list words, slot-major
+	__shared__ uint32_t ovf;          // some tile of the brick has no stored list
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const BrickSel bs = brick_select<1, VBX, VBY, VBZ>(P, nbx, nby, nbz);
 	if (!bs.live) return;  // uniform per workgroup
 	const BrickTab T = {cstart, gbeg, bstart};
 	block_tables(P, bs, T, wsum);
 	const uint32_t total = cstart[VNRC], n_i = bstart[NBC];
-	if (total > (uint32_t)VCAPJ) return;  // unstaged brick: evaluated directly every step, no lists
+	uint32_t* const rec = P.vl_rec + (size_t)bs.id * VREC;
+	if (total > (uint32_t)VCAPJ) {  // unstaged brick: evaluated directly every step, no lists
+		if (tid == 0) rec[VREC_FLAGS] = 0;
+		return;
+	}
+	// the brick's record: what the force pass would otherwise recompute every step (cell loads, two scans, six barriers)
+	for (int c = tid; c <= VNRC; c += NT) rec[c] = cstart[c];
+	for (int c = tid; c < VNRC; c += NT) rec[VREC_GBEG + c] = gbeg[c];
+	if (tid == 0) {
+		rec[VREC_NI] = n_i;
+		ovf = (n_i > (uint32_t)(VMAXT * 64)) ? 1u : 0u;
+	}
 	// brick-relative FP32 positions (origin = low corner of the region's first cell)
 	const double ox = P.g.bmin[0] + (double)(bs.x0 - 2) * P.g.clen[0];
 	const double oy = P.g.bmin[1] + (double)(bs.y0 - 2) * P.g.clen[1];
@@ -475,6 +495,8 @@ __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int n
 			const int rcell = ((cz + 1) * RY + (cy + 1)) * RX + (cx + 1);
 			const uint32_t ii = cstart[rcell] + (it - bstart[lo]);
 			const int rowbase = (cz * RY + cy) * RX + cx;
+			P.vl_ii[(size_t)bs.id * (VMAXT * 64) + it] = (uint16_t)ii;
+			P.vl_gi[(size_t)bs.id * (VMAXT * 64) + it] = gbeg[rcell] + (it - bstart[lo]);
 			const f32x2 xi = {fx[ii], fx[ii]}, yi = {fy[ii], fy[ii]}, zi = {fz[ii], fz[ii]};
 			const uint32_t wb = (uint32_t)tid * 2u;  // byte offset of this lane inside a window row (rows of ROWB = NT * 2 bytes)
 			constexpr uint32_t ROWB = (uint32_t)NT * 2u;
@@ -546,12 +568,17 @@ __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int n
 		uint32_t mine = (cnt + 3u) >> 2, nw = max(mine, 4u);
 		for (int o = 32; o > 0; o >>= 1) nw = max(nw, (uint32_t)__shfl_xor((int)nw, o));
 		if (nw > (uint32_t)VMAXW) {
-			if (lane == 0) P.vl_nw[tile_g] = 0xff;  // overflow (very dense neighbourhood): direct evaluation every step
+			if (lane == 0) {
+				P.vl_nw[tile_g] = 0xff;  // overflow (very dense neighbourhood): direct evaluation every step
+				ovf = 1u;
+			}
 		} else {
 			for (uint32_t w = mine; w < nw; ++w) wp[(size_t)w * 64] = dummy;
 			if (lane == 0) P.vl_nw[tile_g] = (uint8_t)nw;
 		}
 	}
+	__syncthreads();
+	if (tid == 0) rec[VREC_FLAGS] = ovf ? 0u : 1u;
 }
 
 // ---- REUSE, one brick per workgroup (reference implementation of the pipeline below; LS1_VL_ONE_BRICK_PER_WG) ---------
@@ -574,13 +601,33 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet(ForceParams P, int n
 		return;
 	}
 	const ListHead head = load_list_head(P, bs.id, wv, lane);  // independent of everything staged below: issued first
-	const BrickTab T = {cstart, gbeg, bstart};
-	block_tables(P, bs, T, wsum);
-	const bool staged = cstart[VNRC] <= (uint32_t)VCAPJ;
-	if (staged) stage_positions(P, T, sx, sy, sz);
-	__syncthreads();
 	Totals tot = {0., 0., 0., 0.};
-	brick_forces<SHIFT>(P, T, sx, sy, sz, bs.id, staged, head, tot);
+	uint32_t* const rec = P.vl_rec + (size_t)bs.id * VREC;
+	// own LDS slot / global index of the first pass, issued together with the list head and the flags (reads of valid memory
+	// whatever the flags say): nothing the pair loop needs is requested after the staging barrier
+	const uint16_t* const f_ii = P.vl_ii + (size_t)bs.id * (VMAXT * 64);
+	const uint32_t* const f_gi = P.vl_gi + (size_t)bs.id * (VMAXT * 64);
+	const uint32_t ii0 = f_ii[tid], gi0 = f_gi[tid];
+	if (rec[VREC_FLAGS] & 1u) {  // uniform per workgroup
+		// regular brick (staged, every tile has its list): cell table and own indices come from the build's record — no cell
+		// loads, no scans, no table search; the only barrier of the workgroup is the one behind the staging
+		const BrickTab R = {rec, rec + VREC_GBEG, nullptr};
+		stage_positions(P, R, sx, sy, sz);
+		if (tid == 0) {
+			cstart[VNRC] = rec[VNRC];
+			bstart[VNBC] = rec[VREC_NI];
+		}
+		__syncthreads();
+		const BrickTab T = {cstart, gbeg, bstart};  // (only the two totals are read on this path)
+		brick_forces<SHIFT>(P, T, sx, sy, sz, bs.id, true, head, tot, f_ii, f_gi, ii0, gi0);
+	} else {
+		const BrickTab T = {cstart, gbeg, bstart};
+		block_tables(P, bs, T, wsum);
+		const bool staged = cstart[VNRC] <= (uint32_t)VCAPJ;
+		if (staged) stage_positions(P, T, sx, sy, sz);
+		__syncthreads();
+		brick_forces<SHIFT>(P, T, sx, sy, sz, bs.id, staged, head, tot);
+	}
 	store_partials(P, tot, red);
 }
 

@@ -500,10 +500,11 @@ __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int n
 			const f32x2 xi = {fx[ii], fx[ii]}, yi = {fy[ii], fy[ii]}, zi = {fz[ii], fz[ii]};
 			const uint32_t wb = (uint32_t)tid * 2u;  // byte offset of this lane inside a window row (rows of ROWB = NT * 2 bytes)
 			constexpr uint32_t ROWB = (uint32_t)NT * 2u;
+			static_assert((ROWB & (ROWB - 1u)) == 0u, "the slot address is formed with an OR");
 			char* const winb = reinterpret_cast<char*>(win);
 			// one candidate: unconditional store of its offset at slot cnt & 7, cnt advances on a hit (a miss is overwritten)
 			auto put = [&](uint32_t j, bool hit) {
-				*reinterpret_cast<uint16_t*>(winb + ((cnt & 7u) * ROWB + wb)) = (uint16_t)(j * 8u);
+				*reinterpret_cast<uint16_t*>(winb + (((cnt & 7u) * ROWB) | wb)) = (uint16_t)(j * 8u);  // (v_and + v_lshl_or)
 				cnt += hit ? 1u : 0u;
 			};
 			auto flush = [&](uint32_t before) {

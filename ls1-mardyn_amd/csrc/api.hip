@@ -105,6 +105,8 @@ static void free_mol(ls1hip_ctx* c) {
 	c->vl_ready = false;
 	dfree(c->alt_x); dfree(c->alt_y); dfree(c->alt_z);
 	dfree(c->d_vl_words); dfree(c->d_vl_nw); dfree(c->d_vl_rec); dfree(c->d_vl_ii); dfree(c->d_vl_gi);
+	dfree(c->seam_a_buf);
+	c->seam_a_cap = 0;
 	c->vl_words_cap = c->vl_tiles_cap = 0;
 	c->pos_x = c->pos_y = c->pos_z = nullptr;
 	dfree(c->d_key); dfree(c->d_rank); dfree(c->d_perm); dfree(c->d_ckey); dfree(c->d_idk);
@@ -1972,22 +1974,37 @@ extern "C" int ls1hip_soa_forces(ls1hip_ctx* c, const int cell_dims[3], const ui
 	uint32_t *dk = nullptr, *db = nullptr, *de = nullptr;
 	int rc = 0;
 	const size_t npart = n / 64 + 16;
-	(rc = dalloc(c, &dx, n)) || (rc = dalloc(c, &dy, n)) || (rc = dalloc(c, &dz, n)) || (rc = dalloc(c, &dc, n)) ||
-		(rc = dalloc(c, &dk, n)) || (rc = dalloc(c, &db, ncells)) || (rc = dalloc(c, &de, ncells)) ||
-		(rc = dalloc(c, &fx, n)) || (rc = dalloc(c, &fy, n)) || (rc = dalloc(c, &fz, n)) || (rc = dalloc(c, &vx, n)) ||
-		(rc = dalloc(c, &vy, n)) || (rc = dalloc(c, &vz, n)) || (rc = dalloc(c, &part, npart * 4));
-	if (!rc && rot)
-		(rc = dalloc(c, &d0, n)) || (rc = dalloc(c, &d1, n)) || (rc = dalloc(c, &d2, n)) || (rc = dalloc(c, &d3, n)) ||
-			(rc = dalloc(c, &mx, n)) || (rc = dalloc(c, &my, n)) || (rc = dalloc(c, &mz, n));
-	auto cleanup = [&]() {
-		dfree(dx); dfree(dy); dfree(dz); dfree(d0); dfree(d1); dfree(d2); dfree(d3); dfree(dc); dfree(dk); dfree(db);
-		dfree(de); dfree(fx); dfree(fy); dfree(fz); dfree(mx); dfree(my); dfree(mz); dfree(vx); dfree(vy); dfree(vz);
-		dfree(part);
-	};
-	if (rc) {
-		cleanup();
-		return rc;
+	// one persistent, grow-only device arena for the 21 arrays of a traversal (they were allocated and freed per
+	// call — a few ms of hipMalloc / hipFree per time step of the driver)
+	{
+		auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+		const size_t nd = al(n * 8), ni = al(n * 4), nc4 = al(ncells * 4);
+		const size_t need = nd * (3 + 3 + 3 + (rot ? 4 + 3 : 0)) + ni * 2 + nc4 * 2 + al(npart * 4 * 8);
+		if (need > c->seam_a_cap) {
+			dfree(c->seam_a_buf);
+			c->seam_a_cap = 0;
+			const size_t cap = need + need / 4;
+			if ((rc = dalloc(c, &c->seam_a_buf, cap))) return rc;
+			c->seam_a_cap = cap;
+		}
+		char* p = c->seam_a_buf;
+		auto take = [&](size_t bytes) {
+			char* q = p;
+			p += bytes;
+			return q;
+		};
+		dx = (double*)take(nd); dy = (double*)take(nd); dz = (double*)take(nd);
+		fx = (double*)take(nd); fy = (double*)take(nd); fz = (double*)take(nd);
+		vx = (double*)take(nd); vy = (double*)take(nd); vz = (double*)take(nd);
+		if (rot) {
+			d0 = (double*)take(nd); d1 = (double*)take(nd); d2 = (double*)take(nd); d3 = (double*)take(nd);
+			mx = (double*)take(nd); my = (double*)take(nd); mz = (double*)take(nd);
+		}
+		dc = (int32_t*)take(ni); dk = (uint32_t*)take(ni);
+		db = (uint32_t*)take(nc4); de = (uint32_t*)take(nc4);
+		part = (double*)take(al(npart * 4 * 8));
 	}
+	auto cleanup = [&]() {};
 	auto up = [&](void* d, const void* h, size_t bytes) { return bytes ? hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) : hipSuccess; };
 	hipError_t e = hipSuccess;
 	if ((e = up(dx, hx.data(), n * 8)) || (e = up(dy, hy.data(), n * 8)) || (e = up(dz, hz.data(), n * 8)) ||

@@ -182,6 +182,8 @@ struct ls1hip_ctx {
 	double rc_list = 0.;  // rc + skin: cutoff of the cell grid, the halo shell and the lists
 	uint64_t* d_vl_words = nullptr;
 	uint8_t* d_vl_nw = nullptr;
+	char* seam_a_buf = nullptr;  // persistent arena of ls1hip_soa_forces (seam A)
+	size_t seam_a_cap = 0;
 	uint32_t* d_vl_rec = nullptr;
 	uint16_t* d_vl_ii = nullptr;
 	uint32_t* d_vl_gi = nullptr;

@@ -2037,7 +2037,22 @@ extern "C" int ls1hip_soa_forces(ls1hip_ctx* c, const int cell_dims[3], const ui
 	uint32_t nblocks = 0;
 	launch_clear_macro(c->d_cnt, c->stream);
 	if (n) {
-		launch_force_generic(P, c->one_clj, true, rot, c->stream, &nblocks);
+		// the brick kernels traverse exactly the non-halo cells (their which = 0), as the generic kernel does with which = 3;
+		// the per-molecule virial (Vi) exists in the multi-site brick kernel and the generic kernel only
+		bool done = false;
+		const double inner_cells = (double)P.g.box[0] * P.g.box[1] * P.g.box[2];
+		const double mean_per_cell = inner_cells > 0 ? (double)n / (double)ncells : 0.;
+		if (c->opt_force_kernel != LS1HIP_FK_GENERIC && !c->opt_count_pairs) {
+			ForceParams Q = P;
+			Q.which = 0;
+			if (c->one_clj && !Vi)
+				done = launch_force_lj(Q, c->stream, &nblocks, part, npart, (int)c->opt_lj_split, mean_per_cell, &c->brick_lists);
+			else if (!c->one_clj)
+				done = launch_force_ms(Q, Vi != nullptr, rot, c->h_ct.ncomp == 1, c->stream, &nblocks, npart, mean_per_cell,
+									   &c->brick_lists);
+		}
+		c->last_force_kernel = done ? (c->one_clj ? LS1HIP_FK_LDS_LIST : LS1HIP_FK_MS_BRICK) : LS1HIP_FK_GENERIC;
+		if (!done) launch_force_generic(P, c->one_clj, true, rot, c->stream, &nblocks);
 		launch_force_reduce(c->d_cnt, part, nblocks, c->d_stage, c->stream, ReduceMode());
 	}
 	rc = sync_counters(c);

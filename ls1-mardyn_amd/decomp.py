@@ -192,6 +192,19 @@ class HaloExchanger:
     def _ptr(self, t):
         return t.data_ptr()
 
+    def _buffer(self, which, n, device):
+        """persistent, grow-only message buffers (one for all outgoing, one for all incoming messages of an exchange): no
+        allocator traffic in the step loop.  Reuse across exchanges is safe: every exchange ends with import_done, which
+        returns after the engine has consumed the receive buffer, and the sends have been waited for."""
+        if not hasattr(self, "_bufs"):
+            self._bufs = {}
+        key = (which, str(device))
+        t = self._bufs.get(key)
+        if t is None or t.numel() < n:
+            t = self._torch.empty(int(n * 1.25) + 1024, dtype=self._torch.float64, device=device)
+            self._bufs[key] = t
+        return t[:n]
+
     def exchange(self, kind: int, overlap_fn=None):
         """Counts -> all_gather; payload -> one message per peer.  `overlap_fn` (optional) is called after the sends
         and receives have been posted and before they are waited for (inner-cell force launch goes here)."""
@@ -238,7 +251,7 @@ class HaloExchanger:
         self_copies = []  # (send view, peer) of loopback messages when the transport cannot send to the own rank (gloo)
         self_p2p = self._self_p2p_ok()
         if tot_out:
-            sbuf = torch.empty(tot_out * w, dtype=torch.float64, device=self.device)
+            sbuf = self._buffer("s", tot_out * w, self.device)
             order = [d for p in self.peers for d in self._outgoing[p] if counts[d]]
             self.engine.export_pack_dirs(kind, order, self._ptr(sbuf), tot_out)
             if self.stage:
@@ -254,7 +267,7 @@ class HaloExchanger:
                         ops.append(dist.P2POp(dist.isend, view, self.dc.real_rank(p), group=self.group))
                     off += n_out[p]
         if tot_in:
-            rbuf = torch.empty(tot_in * w, dtype=torch.float64, device="cpu" if self.stage else self.device)
+            rbuf = self._buffer("r", tot_in * w, "cpu" if self.stage else self.device)
             off = 0
             for p in self.peers:
                 if n_in[p]:
@@ -293,7 +306,6 @@ class HaloExchanger:
             if not self.peers:
                 raise
             self._deferred = self._deferred or e
-        del sbuf, rbuf
 
 
 class DistributedSimulation:

@@ -166,6 +166,10 @@ int ls1hip_download_forces(ls1hip_ctx* ctx, size_t cap, double* F, double* M, do
 /* Leapfrog::eventNewTimestep -> FullMolecule::upd_preF (integrators/Leapfrog.cpp:48-64,
  * molecules/FullMolecule.cpp:334-364): v += dt/2m F; r += dt v; quaternion / L half steps. */
 int ls1hip_kick_drift(ls1hip_ctx* ctx, double dt);
+/* ls1hip_scale_velocities(beta_trans, beta_rot) followed by ls1hip_kick_drift(dt) in ONE pass over the molecules (what
+ * Simulation::simulate does between two steps of an NVT run: VelocityScalingThermostat::apply, Simulation.cpp:1108-1131, then
+ * Integrator::eventNewTimestep); the arithmetic is that of the two separate calls, operation for operation. */
+int ls1hip_scale_kick_drift(ls1hip_ctx* ctx, double beta_trans, double beta_rot, double dt);
 
 /* LinkedCells::update (LinkedCells.cpp:243-356): re-sort owned molecules into cells; molecules that left the box
  * through a side whose neighbor_rank is this rank are wrapped (DomainDecompBase::handleDomainLeavingParticles,
@@ -192,6 +196,14 @@ int ls1hip_forces(ls1hip_ctx* ctx, int which, double* upot, double* virial);
 /* Leapfrog::eventForcesCalculated -> FullMolecule::upd_postF (Leapfrog.cpp:66-150, FullMolecule.cpp:366-389):
  * v += dt_half/m F; L += dt_half M; returns sum m v^2, sum I w^2, N, rotational DOF (thermostat 0). */
 int ls1hip_kick(ls1hip_ctx* ctx, double dt_half, double* summv2, double* sumIw2, uint64_t* n, uint64_t* rot_dof);
+/* The kinetic sums of the last ls1hip_kick, for callers that queued it with NULL outputs (asynchronously) and fetch later. */
+int ls1hip_kinetic_sums(ls1hip_ctx* ctx, double* summv2, double* sumIw2, uint64_t* n, uint64_t* rot_dof);
+/* Overlap of host and device work around a traversal: ls1hip_forces / ls1hip_forces_list with upot = virial = NULL only queue
+ * the kernels.  ls1hip_traversal_mark queues a copy of the traversal's sums behind them; ls1hip_traversal_sums waits for THAT
+ * copy only — whatever was queued after the mark (typically the post-force ls1hip_kick with NULL outputs) keeps running on
+ * the device while the host goes on with U_pot and the virial (what VectorizedCellProcessor::endTraversal publishes). */
+int ls1hip_traversal_mark(ls1hip_ctx* ctx);
+int ls1hip_traversal_sums(ls1hip_ctx* ctx, double* upot, double* virial);
 
 /* Force pass that consumes the forces at once (reduced-memory mode; the reference's counterpart is the RMM pair
  * VCP1CLJRMM::processCell* + LeapfrogRMM, particleContainer/adapter/VCP1CLJRMM.cpp:241-369, integrators/LeapfrogRMM.cpp):

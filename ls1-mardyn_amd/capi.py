@@ -44,6 +44,10 @@ SYMBOLS = {
     "ls1hip_download_state": (C.c_int, [C.c_void_p, C.c_size_t, _u64p, _i32p, _dp, _dp, _dp, _dp]),
     "ls1hip_download_forces": (C.c_int, [C.c_void_p, C.c_size_t, _dp, _dp, _dp]),
     "ls1hip_kick_drift": (C.c_int, [C.c_void_p, C.c_double]),
+    "ls1hip_scale_kick_drift": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
+    "ls1hip_kinetic_sums": (C.c_int, [C.c_void_p, _dp, _dp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "ls1hip_traversal_mark": (C.c_int, [C.c_void_p]),
+    "ls1hip_traversal_sums": (C.c_int, [C.c_void_p, _dp, _dp]),
     "ls1hip_kick_then_kick_drift": (C.c_int, [C.c_void_p, C.c_double]),
     "ls1hip_rebin": (C.c_int, [C.c_void_p]),
     "ls1hip_halo": (C.c_int, [C.c_void_p]),

@@ -184,6 +184,8 @@ extern "C" int ls1hip_destroy(ls1hip_ctx* c) {
 	if (c->stream2) hipStreamDestroy(c->stream2);
 	if (c->ev_owned) hipEventDestroy(c->ev_owned);
 	if (c->ev_halo) hipEventDestroy(c->ev_halo);
+	if (c->ev_mark) hipEventDestroy(c->ev_mark);
+	if (c->h_mark) hipHostFree(c->h_mark);
 	delete c;
 	return LS1HIP_OK;
 }
@@ -1109,7 +1111,12 @@ static int track_unfused_drift(ls1hip_ctx* c, double dt) {
 	return LS1HIP_OK;
 }
 
-extern "C" int ls1hip_kick_drift(ls1hip_ctx* c, double dt) {
+static int kick_drift_impl(ls1hip_ctx* c, double dt, int pre_scale, double bt, double br);
+extern "C" int ls1hip_kick_drift(ls1hip_ctx* c, double dt) { return kick_drift_impl(c, dt, 0, 1., 1.); }
+extern "C" int ls1hip_scale_kick_drift(ls1hip_ctx* c, double beta_trans, double beta_rot, double dt) {
+	return kick_drift_impl(c, dt, 1, beta_trans, beta_rot);
+}
+static int kick_drift_impl(ls1hip_ctx* c, double dt, int pre_scale, double bt, double br) {
 	if (!c) return LS1HIP_EINVAL;
 	REQUIRE(c, c->cap_real, "no molecules uploaded");
 	REQUIRE(c, !c->fused_split, "a fused inner pass is waiting for its boundary pass");
@@ -1121,11 +1128,15 @@ extern "C" int ls1hip_kick_drift(ls1hip_ctx* c, double dt) {
 	}
 	TimedScope ts(c, c->t_integrate);
 	if (c->vl_ready) {
-		launch_kick_drift(integ_args_lists(c, dt), c->stream);
+		IntegArgs a = integ_args_lists(c, dt);
+		a.pre_scale = pre_scale; a.pre_bt = bt; a.pre_br = br;
+		launch_kick_drift(a, c->stream);
 		int rcb = track_unfused_drift(c, dt);
 		if (rcb) return rcb;
 	} else {
-		launch_kick_drift(integ_args(c, dt), c->stream);
+		IntegArgs a = integ_args(c, dt);
+		a.pre_scale = pre_scale; a.pre_bt = bt; a.pre_br = br;
+		launch_kick_drift(a, c->stream);
 	}
 	HIPCHK(c, hipGetLastError());
 	c->binned = false;
@@ -1177,6 +1188,44 @@ extern "C" int ls1hip_kick(ls1hip_ctx* c, double dt_half, double* summv2, double
 		if (n) *n = c->h_cnt->kin_n;
 		if (rot_dof) *rot_dof = c->h_cnt->kin_rotdof;
 	}
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_kinetic_sums(ls1hip_ctx* c, double* summv2, double* sumIw2, uint64_t* n, uint64_t* rot_dof) {
+	if (!c) return LS1HIP_EINVAL;
+	HIPCHK(c, hipSetDevice(c->device));
+	int rc = sync_counters(c);
+	if (rc) return rc;
+	if (summv2) *summv2 = c->h_cnt->kin[0];
+	if (sumIw2) *sumIw2 = c->h_cnt->kin[1];
+	if (n) *n = c->h_cnt->kin_n;
+	if (rot_dof) *rot_dof = c->h_cnt->kin_rotdof;
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_traversal_mark(ls1hip_ctx* c) {
+	if (!c) return LS1HIP_EINVAL;
+	HIPCHK(c, hipSetDevice(c->device));
+	if (!c->h_mark) {
+		void* h = nullptr;
+		HIPCHK(c, hipHostMalloc(&h, sizeof(DevCounters), hipHostMallocDefault));
+		c->h_mark = (DevCounters*)h;
+		HIPCHK(c, hipEventCreateWithFlags(&c->ev_mark, hipEventDisableTiming));
+	}
+	HIPCHK(c, hipMemcpyAsync(c->h_mark, c->d_cnt, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipEventRecord(c->ev_mark, c->stream));
+	return LS1HIP_OK;
+}
+
+extern "C" int ls1hip_traversal_sums(ls1hip_ctx* c, double* upot, double* virial) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, c->h_mark, "no traversal was marked (ls1hip_traversal_mark)");
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipEventSynchronize(c->ev_mark));
+	if (c->h_mark->err_overflow)
+		FAIL(c, LS1HIP_ENOMEM, "device buffer overflow (%u records dropped): halo/export capacity exceeded", c->h_mark->err_overflow);
+	if (c->h_mark->err_lost) FAIL(c, LS1HIP_ELOST, "%u molecule(s) left the halo region of this rank", c->h_mark->err_lost);
+	macro_to_upot_virial(c->h_mark, upot, virial);
 	return LS1HIP_OK;
 }
 

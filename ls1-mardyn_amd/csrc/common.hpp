@@ -163,6 +163,8 @@ struct ls1hip_ctx {
 	uint32_t n_shell = 0;
 	ls1::DevCounters* d_cnt = nullptr;
 	ls1::DevCounters* h_cnt = nullptr;  // pinned mirror
+	ls1::DevCounters* h_mark = nullptr;  // pinned mirror of ls1hip_traversal_mark
+	hipEvent_t ev_mark = nullptr;
 	double* d_partials = nullptr;
 	double* d_stage = nullptr;  // [128][4] second-stage reduction buffer
 	size_t partials_cap = 0;
@@ -354,6 +356,10 @@ struct IntegArgs {
 	bool has_rot;
 	double dt;
 	double* vmax_part;  // list mode: per-workgroup max |v_drift|^2 of a kick + drift pass (null otherwise)
+	// kick + drift passes: velocity scaling of the thermostat applied to v / D as they are read (same arithmetic as a separate
+	// k_scale pass before: v * beta, then the kick), 0 = off, 1 = factors below, 2 = factors from cnt->beta
+	int pre_scale = 0;
+	double pre_bt = 1., pre_br = 1.;
 };
 void launch_bound_update(DevCounters* cnt, const double* vmax_part, uint32_t nblocks, double dt, double limit, bool fresh, uint32_t seq,
 						 volatile uint32_t* flag, hipStream_t s);

@@ -38,9 +38,20 @@ __global__ void __launch_bounds__(ITPB) k_kick_drift(IntegArgs a) {
 	const double dt = a.dt, dt_halve = .5 * dt;
 	const int c = HAS_ROT ? a.mol.cid[p] : (a.ct->ncomp > 1 ? a.mol.cid[p] : 0);
 	const double dtInv2m = dt_halve / a.ct->mass[c];
-	double vx = a.mol.vx[p] + dtInv2m * a.frc.Fx[p];
-	double vy = a.mol.vy[p] + dtInv2m * a.frc.Fy[p];
-	double vz = a.mol.vz[p] + dtInv2m * a.frc.Fz[p];
+	double bt = 1., br = 1.;
+	if (a.pre_scale) {  // VelocityScalingThermostat::apply folded into this pass (uniform branch)
+		bt = a.pre_scale == 2 ? a.cnt->beta[0] : a.pre_bt;
+		br = a.pre_scale == 2 ? a.cnt->beta[1] : a.pre_br;
+	}
+	double vx = a.mol.vx[p], vy = a.mol.vy[p], vz = a.mol.vz[p];
+	if (a.pre_scale) {
+		vx *= bt;
+		vy *= bt;
+		vz *= bt;
+	}
+	vx += dtInv2m * a.frc.Fx[p];
+	vy += dtInv2m * a.frc.Fy[p];
+	vz += dtInv2m * a.frc.Fz[p];
 	a.mol.vx[p] = vx;
 	a.mol.vy[p] = vy;
 	a.mol.vz[p] = vz;
@@ -51,6 +62,7 @@ __global__ void __launch_bounds__(ITPB) k_kick_drift(IntegArgs a) {
 	if (HAS_ROT) {
 		double q[4] = {a.mol.q0[p], a.mol.q1[p], a.mol.q2[p], a.mol.q3[p]};
 		V3 D = {a.mol.Dx[p], a.mol.Dy[p], a.mol.Dz[p]};
+		if (a.pre_scale) D = {D.x * br, D.y * br, D.z * br};
 		const V3 invI = {a.ct->invI[c][0], a.ct->invI[c][1], a.ct->invI[c][2]};
 		V3 w = rotate_inv(rot_of(q[0], q[1], q[2], q[3]), D);
 		w = {w.x * invI.x, w.y * invI.y, w.z * invI.z};
@@ -210,18 +222,33 @@ void launch_kick(const IntegArgs& a, hipStream_t s, uint32_t* nblocks) {
 	else hipLaunchKernelGGL(k_kick<false>, dim3(nb), dim3(ITPB), 0, s, a);
 }
 
-__global__ void __launch_bounds__(256) k_kin_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, double target_T,
+// One workgroup of RTPB threads over the per-block partials, four independent partial rows in flight per thread (at 10^8
+// molecules there are 4 * 10^5 rows: with 256 threads and one row per trip this kernel took 0.7 ms).
+constexpr int RTPB = 1024;
+__global__ void __launch_bounds__(RTPB) k_kin_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, double target_T,
 													 double* log) {
 	double v[3] = {0., 0., 0.};
-	for (uint32_t b = threadIdx.x; b < nblocks; b += 256)
+	uint32_t b = threadIdx.x;
+	for (; b + 3u * RTPB < nblocks; b += 4u * RTPB) {
+		double t[4][3];
+#pragma unroll
+		for (int u = 0; u < 4; ++u)
+			for (int k = 0; k < 3; ++k) t[u][k] = partials[(size_t)(b + (uint32_t)u * RTPB) * 4 + k];
+		for (int k = 0; k < 3; ++k) v[k] += (t[0][k] + t[1][k]) + (t[2][k] + t[3][k]);
+	}
+	for (; b < nblocks; b += RTPB)
 		for (int k = 0; k < 3; ++k) v[k] += partials[(size_t)b * 4 + k];
-	__shared__ double red[4][3];
+	__shared__ double red[RTPB / 64][3];
 	for (int k = 0; k < 3; ++k) v[k] = wave_sum_i(v[k]);
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	if (lane == 0)
 		for (int k = 0; k < 3; ++k) red[w][k] = v[k];
 	__syncthreads();
 	if (threadIdx.x == 0) {
+		for (int i = 1; i < RTPB / 64; ++i)
+			for (int k = 0; k < 3; ++k) red[0][k] += red[i][k];
+		for (int i = 1; i < 4; ++i)
+			for (int k = 0; k < 3; ++k) red[i][k] = 0.;
 		cnt->kin[0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
 		cnt->kin[1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
 		cnt->kin_n = cnt->n_real;
@@ -271,16 +298,22 @@ void launch_scale(const IntegArgs& a, double beta_trans, double beta_rot, bool f
 
 // List mode, unfused drifts: advance the displacement bound by dt * max |v| of this pass and publish the rebuild flag
 // (the fused force passes do the same inside k_force_reduce2).
-__global__ void __launch_bounds__(256) k_bound_update(DevCounters* cnt, const double* vmax_part, uint32_t nblocks, double dt, double limit,
+__global__ void __launch_bounds__(RTPB) k_bound_update(DevCounters* cnt, const double* vmax_part, uint32_t nblocks, double dt, double limit,
 												  int fresh, uint32_t seq, volatile uint32_t* flag) {
 	double m = 0.;
-	for (uint32_t b = threadIdx.x; b < nblocks; b += 256) m = fmax(m, vmax_part[b]);
-	__shared__ double red[4];
+	uint32_t b = threadIdx.x;
+	for (; b + 3u * RTPB < nblocks; b += 4u * RTPB) {
+		const double t0 = vmax_part[b], t1 = vmax_part[b + RTPB], t2 = vmax_part[b + 2u * RTPB], t3 = vmax_part[b + 3u * RTPB];
+		m = fmax(m, fmax(fmax(t0, t1), fmax(t2, t3)));
+	}
+	for (; b < nblocks; b += RTPB) m = fmax(m, vmax_part[b]);
+	__shared__ double red[RTPB / 64];
 	for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o));
 	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+		m = 0.;
+		for (int i = 0; i < RTPB / 64; ++i) m = fmax(m, red[i]);
 		const double b = (fresh ? 0. : cnt->vl_bound) + dt * sqrt(m);
 		cnt->vl_bound = b;
 		if (flag) {
@@ -292,12 +325,12 @@ __global__ void __launch_bounds__(256) k_bound_update(DevCounters* cnt, const do
 }
 void launch_bound_update(DevCounters* cnt, const double* vmax_part, uint32_t nblocks, double dt, double limit, bool fresh, uint32_t seq,
 						 volatile uint32_t* flag, hipStream_t s) {
-	hipLaunchKernelGGL(k_bound_update, dim3(1), dim3(256), 0, s, cnt, vmax_part, nblocks, dt, limit, fresh ? 1 : 0, seq, flag);
+	hipLaunchKernelGGL(k_bound_update, dim3(1), dim3(RTPB), 0, s, cnt, vmax_part, nblocks, dt, limit, fresh ? 1 : 0, seq, flag);
 }
 
 void launch_kin_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, hipStream_t s, double target_T, double* log) {
 	if (nblocks == 0) return;
-	hipLaunchKernelGGL(k_kin_reduce, dim3(1), dim3(256), 0, s, cnt, partials, nblocks, target_T, log);
+	hipLaunchKernelGGL(k_kin_reduce, dim3(1), dim3(RTPB), 0, s, cnt, partials, nblocks, target_T, log);
 }
 
 }  // namespace ls1

@@ -188,6 +188,23 @@ class DeviceEngine:
     def can_fuse_integration(self) -> bool:
         return bool(self.get_option("can_fuse_integration"))
 
+    def kinetic_sums(self):
+        a = C.c_double(); b = C.c_double(); n = C.c_uint64(); rd = C.c_uint64()
+        self._chk(self.lib.ls1hip_kinetic_sums(self.ctx, C.byref(a), C.byref(b), C.byref(n), C.byref(rd)))
+        return a.value, b.value, n.value, rd.value
+
+    def traversal_mark(self):
+        self._chk(self.lib.ls1hip_traversal_mark(self.ctx))
+
+    def traversal_sums(self):
+        u = C.c_double(); w = C.c_double()
+        self._chk(self.lib.ls1hip_traversal_sums(self.ctx, C.byref(u), C.byref(w)))
+        return u.value, w.value
+
+    def scale_kick_drift(self, beta_trans, beta_rot, dt):
+        """scale_velocities + kick_drift in one pass (ls1hip_scale_kick_drift)"""
+        self._chk(self.lib.ls1hip_scale_kick_drift(self.ctx, float(beta_trans), float(beta_rot), float(dt)))
+
     def kick_then_kick_drift(self, dt: float):
         """Post-force kick of step n fused with the pre-force kick + drift of step n+1 (one pass)."""
         self._chk(self.lib.ls1hip_kick_then_kick_drift(self.ctx, float(dt)))

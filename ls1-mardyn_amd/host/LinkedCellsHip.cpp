@@ -3,7 +3,7 @@
 // real reference LinkedCells object kept as the lazily synced mirror.
 //
 // One time step as the unmodified driver runs it (Simulation.cpp:979-1167) and where each call lands:
-//   _integrator->eventNewTimestep          LeapfrogHip: [velocity scaling with the driver's betas] + ls1hip_kick_drift
+//   _integrator->eventNewTimestep          LeapfrogHip: ls1hip_scale_kick_drift (velocity scaling with the driver's betas + kick + drift, one pass)
 //   _moleculeContainer->update             ls1hip_rebin (wrap + counting sort on the device)
 //   _domainDecomposition->balanceAndExchange   the reference's host loops find an empty region iterator (no-op); the
 //                                          periodic wrap / halo copies they would make are done by ls1hip_rebin / ls1hip_halo
@@ -220,10 +220,19 @@ void LinkedCellsHip::deviceForces(int which) {
 	const bool want = which != 1;
 	long lists = 0;
 	ls1hip_get_option(_ctx, "verlet_ready", &lists);
-	int rc = lists ? ls1hip_forces_list(_ctx, which, 0., want ? &upot : nullptr, want ? &virial : nullptr)
-				   : ls1hip_forces(_ctx, which, want ? &upot : nullptr, want ? &virial : nullptr);
+	// The kernels are only queued here.  With the integrator's post-force kick armed (LeapfrogHip::eventNewTimestep) it is
+	// queued right behind the traversal, and the host waits for the traversal's sums only: the kick runs on the device while the
+	// driver does its host work between traverseCells and eventForcesCalculated (long-range correction, timers, plugins).
+	int rc = lists ? ls1hip_forces_list(_ctx, which, 0., nullptr, nullptr) : ls1hip_forces(_ctx, which, nullptr, nullptr);
 	if (rc) die("ls1hip_forces", rc);
 	if (want) {
+		if ((rc = ls1hip_traversal_mark(_ctx))) die("ls1hip_traversal_mark", rc);
+		if (_armedKick > 0.) {
+			if ((rc = ls1hip_kick(_ctx, _armedKick, nullptr, nullptr, nullptr, nullptr))) die("ls1hip_kick", rc);
+			_armedKick = 0.;
+			_kickQueued = true;
+		}
+		if ((rc = ls1hip_traversal_sums(_ctx, &upot, &virial))) die("ls1hip_traversal_sums", rc);
 		// what VectorizedCellProcessor::endTraversal publishes (VectorizedCellProcessor.cpp:155-156)
 		Domain* domain = global_simulation->getDomain();
 		domain->setLocalUpot(upot);
@@ -313,22 +322,22 @@ void LeapfrogHip::eventNewTimestep(ParticleContainer* moleculeContainer, Domain*
 	ls1hip_ctx* ctx = cont->context();
 	int rc;
 	if (_haveBeta && !domain->NVE()) {
-		// VelocityScalingThermostat::apply of the step just finished (Simulation.cpp:1108-1131), global thermostat
+		// VelocityScalingThermostat::apply of the step just finished (Simulation.cpp:1108-1131), global thermostat — folded into
+		// the same pass over the molecules as transition3to1 + transition1to2 (FullMolecule::upd_preF, Leapfrog.cpp:48-64)
 		if (domain->severalThermostats()) {
 			global_log->error() << "LeapfrogHip: component-wise thermostats are not available on the device path" << std::endl;
 			Simulation::exit(685);
 		}
-		if ((rc = ls1hip_scale_velocities(ctx, domain->getGlobalBetaTrans(), domain->getGlobalBetaRot()))) {
-			global_log->error() << "ls1hip_scale_velocities: " << ls1hip_last_error(ctx) << std::endl;
+		if ((rc = ls1hip_scale_kick_drift(ctx, domain->getGlobalBetaTrans(), domain->getGlobalBetaRot(), _timestepLength))) {
+			global_log->error() << "ls1hip_scale_kick_drift: " << ls1hip_last_error(ctx) << std::endl;
 			Simulation::exit(686);
 		}
-	}
-	// transition3to1 + transition1to2: FullMolecule::upd_preF for every owned molecule (Leapfrog.cpp:48-64)
-	if ((rc = ls1hip_kick_drift(ctx, _timestepLength))) {
+	} else if ((rc = ls1hip_kick_drift(ctx, _timestepLength))) {
 		global_log->error() << "ls1hip_kick_drift: " << ls1hip_last_error(ctx) << std::endl;
 		Simulation::exit(687);
 	}
 	cont->deviceAdvanced();
+	cont->armPostForceKick(0.5 * _timestepLength);
 	_state = STATE_PRE_FORCE_CALCULATION;
 }
 
@@ -338,8 +347,10 @@ void LeapfrogHip::eventForcesCalculated(ParticleContainer* moleculeContainer, Do
 	ls1hip_ctx* ctx = cont->context();
 	double summv2 = 0., sumIw2 = 0.;
 	uint64_t n = 0, rotdof = 0;
-	// transition2to3: upd_postF + the kinetic sums of thermostat 0 (Leapfrog.cpp:66-150)
-	int rc = ls1hip_kick(ctx, 0.5 * _timestepLength, &summv2, &sumIw2, &n, &rotdof);
+	// transition2to3: upd_postF + the kinetic sums of thermostat 0 (Leapfrog.cpp:66-150); normally already queued behind the
+	// traversal by the container (see LinkedCellsHip::deviceForces) and finished by now
+	int rc = cont->takeQueuedKick() ? ls1hip_kinetic_sums(ctx, &summv2, &sumIw2, &n, &rotdof)
+									: ls1hip_kick(ctx, 0.5 * _timestepLength, &summv2, &sumIw2, &n, &rotdof);
 	if (rc) {
 		global_log->error() << "ls1hip_kick: " << ls1hip_last_error(ctx) << std::endl;
 		Simulation::exit(688);

@@ -90,6 +90,12 @@ public:
 	void deviceAdvanced();            // the integrator moved the molecules on the device: the mirror is stale -> emptied
 	void syncMirrorFromDevice();      // refill the mirror with the device state (read-only snapshot for plugins / writers)
 	bool mirrorFresh() const { return _mirrorFresh; }
+	void armPostForceKick(double dt_half) { _armedKick = dt_half; }  // the next complete traversal queues the kick behind itself
+	bool takeQueuedKick() {
+		const bool q = _kickQueued;
+		_kickQueued = false;
+		return q;
+	}
 
 private:
 	void die(const char* what, int rc) const;
@@ -99,6 +105,8 @@ private:
 	LinkedCells _mirror;  // host mirror: the reference's own container (all host-side semantics)
 	ls1hip_ctx* _ctx = nullptr;
 	double _skin = 0.;          // neighbour-list skin handed to ls1hip_set_verlet (0: search every step)
+	double _armedKick = 0.;     // dt / 2 of the integrator's post-force kick, queued behind the next traversal
+	bool _kickQueued = false;   // ... and it has been queued
 	bool _uploaded = false;     // the device holds the molecule set
 	bool _mirrorFresh = true;   // the mirror holds the current molecule set
 	bool _hostDirty = true;     // molecules were added / removed through the host interface since the last upload

@@ -287,3 +287,31 @@ def test_headline_box_1e8_properties():
     p = e.download_velocities().sum(0)
     assert np.max(np.abs(p - psum)) < 1e-9 * np.sqrt(N)
     e.close()
+
+
+def test_scale_kick_drift_is_bitwise_the_two_separate_passes():
+    """ls1hip_scale_kick_drift (thermostat scaling folded into the kick + drift pass, what the seam-B integrator calls) ==
+    ls1hip_scale_velocities + ls1hip_kick_drift, bit for bit — single-site LJ and ethane (angular momenta scaled too)."""
+    for name in ("bcc1clj_3456_nvt10", "ethan_nvt5"):
+        case = MAN[name]
+        ps = inp.read_inp(input_path(case["input"]))
+        st = sorted_phase_space(ps)
+        res = []
+        for fused in (False, True):
+            e = engine_mod.DeviceEngine(0)
+            e.set_components(ps.components, case["rc"])
+            e.set_domain(ps.length)
+            q = st["q"] / np.linalg.norm(st["q"], axis=1, keepdims=True)
+            e.upload(st["ids"], st["cid"], st["r"], st["v"], q, st["D"])
+            e.rebin(); e.halo(); e.forces(0)
+            if fused:
+                e.scale_kick_drift(0.97, 1.04, case["dt"])
+            else:
+                e.scale_velocities(0.97, 1.04)
+                e.kick_drift(case["dt"])
+            s = e.download_state()
+            o = np.argsort(s["ids"], kind="stable")
+            res.append({k: s[k][o] for k in ("r", "v", "q", "D")})
+            e.close()
+        for k in ("r", "v", "q", "D"):
+            assert np.array_equal(res[0][k], res[1][k]), (name, k)

@@ -192,6 +192,9 @@ def main():
     ap.add_argument("--overlap", type=int, default=-1, help="ls1hip_run halo mode: 0 single pass, 1 overlapped, 2 split sequential")
     ap.add_argument("--skin", type=float, default=0.2,
                     help="neighbour-list skin in sigma (list-reuse loop of ls1hip_run, single GPU); 0 = per-step search kernels")
+    ap.add_argument("--precision", choices=("dp", "spdp", "spsp"), default="dp",
+                    help="pair arithmetic of the list force pass: dp = FP64 (the metric's precision, default); spdp / spsp = the "
+                         "reference's single-precision build modes (NOT the headline: dtype says so)")
     ap.add_argument("--no-fuse", action="store_true", help="separate integrator passes instead of the fused force pass")
     ap.add_argument("--decomp", action="store_true",
                     help="diagnostic: run the decomposed (multi-rank) step loop even with one rank")
@@ -283,6 +286,8 @@ def main():
         (sim.engine if sim is not None else eng).set_option("fuse_integration", 0)
     if args.overlap >= 0:
         (sim.engine if sim is not None else eng).set_option("overlap_halo", args.overlap)
+    if args.precision != "dp":
+        (sim.engine if sim is not None else eng).set_option("precision", {"spdp": 1, "spsp": 2}[args.precision])
 
     def run(k):
         if sim is not None:
@@ -366,7 +371,9 @@ def main():
             "metric": BASELINE_METRIC if n == 368 else f"particle-updates/sec (whole node), N={n_total} LJ liquid Argon, rc=2.5\u03c3",
             "value": value, "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"dp": "f64", "spdp": "f32 pair arithmetic, f64 sums and integration (SPDP mode, not the metric's precision)",
+                                           "spsp": "f32 pair arithmetic and sums, f64 integration (SPSP mode, not the metric's precision)"}[args.precision],
+            "data": "synthetic",
             "config": {"workload": f"1CLJ Lennard-Jones liquid, N={n_total} = 2*{n}^3 (global box, split over {world} GPU(s)), "
                                    f"rho*={RHO}, rc={RC} sigma, dt={DT}, T*={TEMP}, NVE full time step (kick-drift, re-bin, halo, "
                                    f"forces, kick) with per-step U_pot / virial / sum mv^2, FP64",

@@ -70,8 +70,12 @@ const char* ls1hip_version(void);
  * "deterministic" (0|1 canonical in-cell order by molecule id),
  * "count_pairs" (0|1 tally molecule pairs / site interactions inside the cutoff for ls1hip_pair_stats — the
  * counters of adapter/FlopCounter.cpp:20-76; forces then use the generic kernel),
- * "last_force_kernel" (read only: kernel family of the last force launch — 1 generic, 2 single-centre LJ brick kernels,
- *   3 multi-site brick kernel; lets callers / tests see a fallback to the generic kernel),
+ * "last_force_kernel" (read only: kernel family of the last force launch — LS1HIP_FK_*: 1 generic, 2 single-centre LJ brick
+ *   kernels, 3 multi-site brick kernel, 4 multi-site site kernel; lets callers / tests see a fallback to the generic kernel),
+ * "precision" (list force pass of the single-centre LJ path: 0 = FP64 (default), 1 = SPDP, 2 = SPSP — the reference's
+ *   MARDYN_SPDP / MARDYN_SPSP build modes, vectorization/RealVec.h, RealAccumVecSPDP.h: pair arithmetic in FP32, sums in
+ *   FP64 / FP32; molecule state, integration and reductions stay FP64; used while every brick of the last list build is
+ *   regular, read-only "precision_in_use" tells),
  * "overlap_halo" (ls1hip_run: 0 = halo, then one traversal of all cells (default, fastest on a single GPU); 1 = inner
  *   cells first, the halo built on a second stream meanwhile, then the boundary cells — the order a transport-driven
  *   multi-rank loop uses; 2 = halo, inner cells, boundary cells on one stream),

@@ -217,6 +217,9 @@ extern "C" int ls1hip_set_option(ls1hip_ctx* c, const char* name, long v) {
 	} else if (n == "overlap_halo") {
 		REQUIRE(c, v >= 0 && v <= 2, "overlap_halo must be 0, 1 or 2");
 		c->opt_overlap_halo = v;
+	} else if (n == "precision") {
+		REQUIRE(c, v >= 0 && v <= 2, "precision must be 0 (FP64), 1 (SPDP) or 2 (SPSP)");
+		c->opt_precision = v;
 	} else if (n == "lj_split") {
 		REQUIRE(c, v == 0 || v == 1 || v == 2 || v == 4 || v == 5 || v == 6, "lj_split must be 0 (auto), 1, 2 (list kernel lanes per molecule), 4, 5 or 6 (MFMA pre-filter variants)");
 		c->opt_lj_split = v;
@@ -237,6 +240,9 @@ extern "C" int ls1hip_get_option(const ls1hip_ctx* c, const char* name, long* v)
 	else if (n == "lj_split") *v = c->opt_lj_split;
 	else if (n == "fuse_integration") *v = c->opt_fuse;
 	else if (n == "overlap_halo") *v = c->opt_overlap_halo;
+	else if (n == "precision") *v = c->opt_precision;
+	else if (n == "verlet_irregular_bricks") *v = c->h_cnt ? (long)c->h_cnt->vl_irregular : 0;  // as of the last build in a single-precision mode
+	else if (n == "precision_in_use") *v = (c->opt_precision && c->vl_ready && c->vl_all_regular) ? c->opt_precision : 0;
 	else if (n == "can_fuse_integration") *v = can_fuse(c) ? 1 : 0;
 	else if (n == "last_force_kernel") *v = c->last_force_kernel;
 	else if (n == "verlet_lists") *v = c->vl_on ? 1 : 0;
@@ -904,6 +910,7 @@ static void fill_force_params(ls1hip_ctx* c, ForceParams& P, int which) {
 	P.vl_rc2 = c->rc_list * c->rc_list;
 	P.vl_words = c->d_vl_words;
 	P.vl_nw = c->d_vl_nw;
+	P.precision = (c->opt_precision && c->vl_all_regular) ? (int)c->opt_precision : 0;
 	P.vl_rec = c->d_vl_rec;
 	P.vl_ii = c->d_vl_ii;
 	P.vl_gi = c->d_vl_gi;
@@ -1386,10 +1393,19 @@ static int verlet_build(ls1hip_ctx* c) {
 	fill_force_params(c, P, 0);
 	P.vl_mode = 1;
 	uint32_t nb = 0;
+	HIPCHK(c, hipMemsetAsync(&c->d_cnt->vl_irregular, 0, sizeof(uint32_t), c->stream));
 	if (!launch_force_verlet(P, c->stream, &nb, c->partials_cap, &c->brick_lists))
 		FAIL(c, LS1HIP_EINVAL, "neighbour lists could not be built for this grid");
 	HIPCHK(c, hipGetLastError());
 	c->vl_builds++;
+	c->vl_all_regular = false;
+	if (c->opt_precision) {
+		// the single-precision force pass serves regular bricks only: it is used while the build reports none of the other kind
+		// (one host round trip per list build, only in this mode)
+		int rs = sync_counters(c);
+		if (rs) return rs;
+		c->vl_all_regular = c->h_cnt->vl_irregular == 0;
+	}
 	return LS1HIP_OK;
 }
 

@@ -51,6 +51,7 @@ struct DevCounters {
 	uint32_t err_overflow; // capacity overflows
 	uint32_t err_ingest;   // uploaded molecules outside the bounding box of this rank / with a wrong component id
 	uint32_t err_ingest_first;  // index (in upload order) of one offending molecule
+	uint32_t vl_irregular;      // list build: bricks without a complete set of stored lists (unstaged, overflow)
 	unsigned long long dist_checks, pairs_in_range;
 	double vmax2;          // list-reuse mode: max |v|^2 of the drift velocities of the current step
 	double vl_bound;       // upper bound of the displacement of any molecule since the neighbour lists were built
@@ -89,6 +90,7 @@ struct ForceParams {
 	double vl_rc2;       // (rc + skin)^2: list cutoff
 	uint64_t* vl_words;  // [brick][tile][word][64 lanes]: 4 u16 LDS byte offsets per word
 	uint8_t* vl_nw;      // [brick][tile]: words per lane in use (wave maximum), 0xff = overflow -> direct evaluation
+	int precision;       // list force pass: 0 FP64, 1 FP32 pair arithmetic with FP64 sums (SPDP), 2 FP32 sums too (SPSP)
 	uint32_t* vl_rec;    // [brick][verlet_record_words()]: region cell table + flags, written by the build
 	uint16_t* vl_ii;     // [brick][tiles * 64]: LDS slot of every owned molecule
 	uint32_t* vl_gi;     // [brick][tiles * 64]: global index of every owned molecule
@@ -127,6 +129,8 @@ struct ls1hip_ctx {
 	// ls1hip_run halo mode: 0 halo, then one pass over all cells (fastest on one GPU: measured 3.50 / 3.52 / 3.60 ms for
 	// modes 0 / 1 / 2); 1 inner-cell pass first with the halo phase on the second stream meanwhile; 2 halo, inner, boundary
 	long opt_overlap_halo = 0;
+	long opt_precision = 0;       // list force pass: 0 FP64 | 1 SPDP | 2 SPSP (used while every brick is regular)
+	bool vl_all_regular = false;  // result of the last list build
 	long opt_fuse = 1;       // ls1hip_run: fuse force + integration between steps when possible
 	// where the CURRENT positions live when not in mol[cur].x/y/z: the force arrays after a fused per-step pass, the second
 	// position buffer (alt_*) in the list-reuse mode; nullptr = mol[cur]

@@ -444,7 +444,10 @@ __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int n
 	const uint32_t total = cstart[VNRC], n_i = bstart[NBC];
 	uint32_t* const rec = P.vl_rec + (size_t)bs.id * VREC;
 	if (total > (uint32_t)VCAPJ) {  // unstaged brick: evaluated directly every step, no lists
-		if (tid == 0) rec[VREC_FLAGS] = 0;
+		if (tid == 0) {
+			rec[VREC_FLAGS] = 0;
+			atomicAdd(&P.cnt->vl_irregular, 1u);
+		}
 		return;
 	}
 	// the brick's record: what the force pass would otherwise recompute every step (cell loads, two scans, six barriers)
@@ -579,7 +582,10 @@ __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int n
 		}
 	}
 	__syncthreads();
-	if (tid == 0) rec[VREC_FLAGS] = ovf ? 0u : 1u;
+	if (tid == 0) {
+		rec[VREC_FLAGS] = ovf ? 0u : 1u;
+		if (ovf) atomicAdd(&P.cnt->vl_irregular, 1u);
+	}
 }
 
 // ---- REUSE, one brick per workgroup (reference implementation of the pipeline below; LS1_VL_ONE_BRICK_PER_WG) ---------
@@ -632,6 +638,218 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet(ForceParams P, int n
 	store_partials(P, tot, red);
 }
 
+
+// ---- REUSE in single precision (the reference's MARDYN_SPSP / MARDYN_SPDP build modes, vectorization/RealVec.h,
+// RealAccumVecSPDP.h; its reduced-memory mode runs in them) -----------------------------------------------------------------
+// Option "precision" = 1 (SPDP: pair arithmetic in FP32, sums in FP64) | 2 (SPSP: FP32 sums).  The molecule state stays FP64
+// in memory and the fused integration epilogue is the FP64 one: only the pair loop changes.  Positions are staged as FP32
+// relative to the region's corner (12 B per molecule: 34 KB, four workgroups per CU), two pairs per packed instruction
+// (v_pk_add / v_pk_mul / v_pk_fma_f32), v_rcp_f32 (1 ulp) without a Newton step.  The list entries (LDS byte offsets of the FP64
+// layout) are halved.  Regular bricks only: the host launches this kernel when the build reported no irregular brick.
+struct SAcc2 {
+	f32x2 fx, fy, fz, slj, vir;
+};
+template <bool SHIFT>
+__device__ __forceinline__ void sp_pair2(f32x2 xi, f32x2 yi, f32x2 zi, f32x2 xj, f32x2 yj, f32x2 zj, float rc2, float sig2, SAcc2& a,
+										 uint32_t& nin) {
+	const f32x2 dx = xi - xj, dy = yi - yj, dz = zi - zj;
+	const f32x2 r2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+	const bool in0 = r2.x < rc2, in1 = r2.y < rc2;
+	// out of range: r2 := 1e30, 1 / r2 = 1e-30 and every LJ term underflows to exactly 0
+	const f32x2 inv = {__builtin_amdgcn_rcpf(in0 ? r2.x : 1.0e30f), __builtin_amdgcn_rcpf(in1 ? r2.y : 1.0e30f)};
+	const f32x2 lj2 = sig2 * inv;
+	const f32x2 lj6 = lj2 * lj2 * lj2;
+	const f32x2 lj12m6 = __builtin_elementwise_fma(lj6, lj6, -lj6);
+	const f32x2 fac = inv * __builtin_elementwise_fma(lj6, lj6, lj12m6);
+	a.fx = __builtin_elementwise_fma(fac, dx, a.fx);
+	a.fy = __builtin_elementwise_fma(fac, dy, a.fy);
+	a.fz = __builtin_elementwise_fma(fac, dz, a.fz);
+	a.slj += lj12m6;
+	a.vir = __builtin_elementwise_fma(fac, r2, a.vir);
+	if (SHIFT) nin += (in0 ? 1u : 0u) + (in1 ? 1u : 0u);
+}
+
+template <bool SHIFT, bool DPACC>
+__global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet_sp(ForceParams P, int nbx, int nby, int nbz) {
+	constexpr int CAPS = VCAPS, NT = VNT, NW = VNW;
+	__shared__ float fpos[3 * CAPS];
+	float* const fx = fpos;
+	float* const fy = fpos + CAPS;
+	float* const fz = fpos + 2 * CAPS;
+	__shared__ double red[VNW][4];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const BrickSel bs = brick_select<1, VBX, VBY, VBZ>(P, nbx, nby, nbz);
+	if (!bs.live) {  // uniform per workgroup
+		if (tid < 4) P.partials[(size_t)blockIdx.x * 4 + tid] = 0.;
+		return;
+	}
+	const ListHead head = load_list_head(P, bs.id, wv, lane);
+	const uint32_t* const rec = P.vl_rec + (size_t)bs.id * VREC;
+	const uint16_t* const f_ii = P.vl_ii + (size_t)bs.id * (VMAXT * 64);
+	const uint32_t* const f_gi = P.vl_gi + (size_t)bs.id * (VMAXT * 64);
+	const uint32_t ii0 = f_ii[tid], gi0 = f_gi[tid];
+	const uint32_t total = rec[VNRC], n_i = rec[VREC_NI];
+	// ---- staging: FP32 relative to the low corner of the region's first cell (as the build does) ------------------------------
+	const double ox = P.g.bmin[0] + (double)(bs.x0 - 2) * P.g.clen[0];
+	const double oy = P.g.bmin[1] + (double)(bs.y0 - 2) * P.g.clen[1];
+	const double oz = P.g.bmin[2] + (double)(bs.z0 - 2) * P.g.clen[2];
+	{
+		constexpr int NR = (VNRC + NT / 16 - 1) / (NT / 16);
+		const uint32_t sub = (uint32_t)tid & 15u;
+		double px[NR][2], py[NR][2], pz[NR][2];
+		uint32_t sdst[NR][2];
+		bool more = false;
+#pragma unroll
+		for (int j = 0; j < NR; ++j) {
+			const int c = (tid >> 4) + j * (NT / 16);
+			uint32_t n = 0, s0 = 0, g0 = 0;
+			if (c < VNRC) {
+				s0 = rec[c];
+				n = rec[c + 1] - s0;
+				g0 = rec[VREC_GBEG + c];
+			}
+			more |= n > 32u;
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				const uint32_t k = sub + 16u * h;
+				const bool ok = k < n;
+				sdst[j][h] = ok ? s0 + k : 0xffffffffu;
+				const uint32_t g = ok ? g0 + k : 0u;
+				px[j][h] = P.x[g];
+				py[j][h] = P.y[g];
+				pz[j][h] = P.z[g];
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < NR; ++j)
+#pragma unroll
+			for (int h = 0; h < 2; ++h)
+				if (sdst[j][h] != 0xffffffffu) {
+					fx[sdst[j][h]] = (float)(px[j][h] - ox);
+					fy[sdst[j][h]] = (float)(py[j][h] - oy);
+					fz[sdst[j][h]] = (float)(pz[j][h] - oz);
+				}
+		if (more) {
+			for (int c = tid >> 4; c < VNRC; c += NT / 16) {
+				const uint32_t s0 = rec[c], n = rec[c + 1] - s0, g0 = rec[VREC_GBEG + c];
+				for (uint32_t k = 32u + sub; k < n; k += 16u) {
+					fx[s0 + k] = (float)(P.x[g0 + k] - ox);
+					fy[s0 + k] = (float)(P.y[g0 + k] - oy);
+					fz[s0 + k] = (float)(P.z[g0 + k] - oz);
+				}
+			}
+		}
+		if (tid < 8) {
+			fx[total + tid] = 1.0e15f;  // far-away dummy slot (r^2 ~ 1e30: fails every cutoff test)
+			fy[total + tid] = 1.0e15f;
+			fz[total + tid] = 1.0e15f;
+		}
+	}
+	__syncthreads();
+	Totals tot = {0., 0., 0., 0.};
+	const float rc2 = (float)P.rc2, sig2 = (float)P.sig2;
+	const double eps24 = P.eps24, shift6 = P.shift6;
+	const char* const fxb = reinterpret_cast<const char*>(fx);
+	for (uint32_t base = 0, pass = 0; base < n_i; base += NT, ++pass) {
+		const uint32_t it = base + (uint32_t)tid;
+		const bool active = it < n_i;
+		const uint32_t tile = pass * NW + (uint32_t)wv;  // wave-uniform; < VMAXT (regular brick)
+		const size_t tile_g = (size_t)bs.id * VMAXT + tile;
+		uint32_t ii = total, gi = 0;
+		if (active) {
+			ii = pass == 0 ? ii0 : (uint32_t)f_ii[it];
+			gi = pass == 0 ? gi0 : f_gi[it];
+		}
+		// own FP64 state for the epilogue: requested before the pair loop
+		double x0 = 0., y0 = 0., z0 = 0., vx0 = 0., vy0 = 0., vz0 = 0.;
+		if (active && P.fuse) {
+			x0 = P.x[gi]; y0 = P.y[gi]; z0 = P.z[gi];
+			vx0 = P.vx[gi]; vy0 = P.vy[gi]; vz0 = P.vz[gi];
+		}
+		const uint32_t nw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pass == 0 ? head.nw : (uint32_t)P.vl_nw[tile_g]));
+		const f32x2 xi = {fx[ii], fx[ii]}, yi = {fy[ii], fy[ii]}, zi = {fz[ii], fz[ii]};
+		const uint64_t* const wp = P.vl_words + tile_g * VMAXW * 64 + lane;
+		const uint32_t last = nw - 1u;
+		uint64_t r0 = head.w0, r1 = head.w1;
+		if (pass != 0) {
+			r0 = load_row(wp);
+			r1 = load_row(wp + 64);
+		}
+		uint64_t r2 = load_row(wp + 128), r3 = load_row(wp + 192);
+		double dfx = 0., dfy = 0., dfz = 0., dslj = 0., dvir = 0.;  // DPACC: FP64 sums
+		SAcc2 acc = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+		uint32_t nin = 0;
+		auto four_pairs = [&](uint64_t cur) {
+			const uint32_t lo32 = (uint32_t)cur, hi32 = (uint32_t)(cur >> 32);
+			// entries are byte offsets of the FP64 layout (8 j): halved for the FP32 arrays
+			const uint32_t o0 = (lo32 & 0xffffu) >> 1, o1 = lo32 >> 17, o2 = (hi32 & 0xffffu) >> 1, o3 = hi32 >> 17;
+			const f32x2 xa = {*reinterpret_cast<const float*>(fxb + o0), *reinterpret_cast<const float*>(fxb + o1)};
+			const f32x2 ya = {*reinterpret_cast<const float*>(fxb + o0 + CAPS * 4), *reinterpret_cast<const float*>(fxb + o1 + CAPS * 4)};
+			const f32x2 za = {*reinterpret_cast<const float*>(fxb + o0 + 2 * CAPS * 4), *reinterpret_cast<const float*>(fxb + o1 + 2 * CAPS * 4)};
+			const f32x2 xb = {*reinterpret_cast<const float*>(fxb + o2), *reinterpret_cast<const float*>(fxb + o3)};
+			const f32x2 yb = {*reinterpret_cast<const float*>(fxb + o2 + CAPS * 4), *reinterpret_cast<const float*>(fxb + o3 + CAPS * 4)};
+			const f32x2 zb = {*reinterpret_cast<const float*>(fxb + o2 + 2 * CAPS * 4), *reinterpret_cast<const float*>(fxb + o3 + 2 * CAPS * 4)};
+			if (DPACC) {
+				SAcc2 w = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+				sp_pair2<SHIFT>(xi, yi, zi, xa, ya, za, rc2, sig2, w, nin);
+				sp_pair2<SHIFT>(xi, yi, zi, xb, yb, zb, rc2, sig2, w, nin);
+				dfx += (double)(w.fx.x + w.fx.y);
+				dfy += (double)(w.fy.x + w.fy.y);
+				dfz += (double)(w.fz.x + w.fz.y);
+				dslj += (double)(w.slj.x + w.slj.y);
+				dvir += (double)(w.vir.x + w.vir.y);
+			} else {
+				sp_pair2<SHIFT>(xi, yi, zi, xa, ya, za, rc2, sig2, acc, nin);
+				sp_pair2<SHIFT>(xi, yi, zi, xb, yb, zb, rc2, sig2, acc, nin);
+			}
+		};
+		for (uint32_t k = 0; k < nw; k += 4) {
+			four_pairs(r0);
+			r0 = load_row(wp + (size_t)min(k + 4u, last) * 64);
+			if (k + 1 < nw) four_pairs(r1);
+			r1 = load_row(wp + (size_t)min(k + 5u, last) * 64);
+			if (k + 2 < nw) four_pairs(r2);
+			r2 = load_row(wp + (size_t)min(k + 6u, last) * 64);
+			if (k + 3 < nw) four_pairs(r3);
+			r3 = load_row(wp + (size_t)min(k + 7u, last) * 64);
+		}
+		if (active) {
+			if (!DPACC) {
+				dfx = (double)(acc.fx.x + acc.fx.y);
+				dfy = (double)(acc.fy.x + acc.fy.y);
+				dfz = (double)(acc.fz.x + acc.fz.y);
+				dslj = (double)(acc.slj.x + acc.slj.y);
+				dvir = (double)(acc.vir.x + acc.vir.y);
+			}
+			const double fxd = eps24 * dfx, fyd = eps24 * dfy, fzd = eps24 * dfz;
+			if (!P.fuse) {
+				P.Fx[gi] = fxd;
+				P.Fy[gi] = fyd;
+				P.Fz[gi] = fzd;
+			} else {  // the FP64 epilogue of brick_forces
+				const double k2 = P.dt_inv2m;
+				double vx = vx0 + k2 * fxd;
+				double vy = vy0 + k2 * fyd;
+				double vz = vz0 + k2 * fzd;
+				tot.kin += P.mass * (vx * vx + vy * vy + vz * vz);
+				vx += k2 * fxd;
+				vy += k2 * fyd;
+				vz += k2 * fzd;
+				P.vx[gi] = vx;
+				P.vy[gi] = vy;
+				P.vz[gi] = vz;
+				tot.vmax2 = fmax(tot.vmax2, vx * vx + vy * vy + vz * vz);
+				P.Fx[gi] = x0 + P.dt * vx;
+				P.Fy[gi] = y0 + P.dt * vy;
+				P.Fz[gi] = z0 + P.dt * vz;
+			}
+			tot.u6 += fma(eps24, dslj, shift6 * (double)nin);
+			tot.vir += eps24 * dvir;
+		}
+	}
+	store_partials(P, tot, red);
+}
+
 bool launch_force_verlet(const ForceParams& p_in, hipStream_t s, uint32_t* nblocks, size_t partials_cap, BrickLists* bl) {
 	ForceParams p = p_in;
 	const Grid& g = p.g;
@@ -652,7 +870,13 @@ bool launch_force_verlet(const ForceParams& p_in, hipStream_t s, uint32_t* nbloc
 	}
 	if ((size_t)nb > partials_cap) return false;
 	*nblocks = (uint32_t)nb;
-	if (shift) hipLaunchKernelGGL((k_force_lj_verlet<true>), dim3((uint32_t)nb), dim3(VNT), 0, s, p, nbx, nby, nbz);
+	if (p.precision == 1) {
+		if (shift) hipLaunchKernelGGL((k_force_lj_verlet_sp<true, true>), dim3((uint32_t)nb), dim3(VNT), 0, s, p, nbx, nby, nbz);
+		else hipLaunchKernelGGL((k_force_lj_verlet_sp<false, true>), dim3((uint32_t)nb), dim3(VNT), 0, s, p, nbx, nby, nbz);
+	} else if (p.precision == 2) {
+		if (shift) hipLaunchKernelGGL((k_force_lj_verlet_sp<true, false>), dim3((uint32_t)nb), dim3(VNT), 0, s, p, nbx, nby, nbz);
+		else hipLaunchKernelGGL((k_force_lj_verlet_sp<false, false>), dim3((uint32_t)nb), dim3(VNT), 0, s, p, nbx, nby, nbz);
+	} else if (shift) hipLaunchKernelGGL((k_force_lj_verlet<true>), dim3((uint32_t)nb), dim3(VNT), 0, s, p, nbx, nby, nbz);
 	else hipLaunchKernelGGL((k_force_lj_verlet<false>), dim3((uint32_t)nb), dim3(VNT), 0, s, p, nbx, nby, nbz);
 	return true;
 }

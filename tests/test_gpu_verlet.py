@@ -246,3 +246,62 @@ def test_verlet_piecewise_unfused_loop_over_many_rebuilds(temp, steps):
     assert b.update() is False
     assert a.update() is True
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("precision,tol_f,tol_traj", [(1, 3e-5, 5e-5), (2, 5e-5, 1e-4)])
+def test_single_precision_list_pass_against_fp64(precision, tol_f, tol_traj):
+    """The reference's MARDYN_SPDP / MARDYN_SPSP build modes as a run-time option of the list force pass ("precision" = 1: FP32
+    pair arithmetic, FP64 sums; 2: FP32 sums too; the molecule state and the integration stay FP64).  Parity is UNPINNED against
+    the reference (no single-precision build of it here): the checks are against this library's FP64 kernels and, over 10 steps,
+    over 20 steps, against its FP64 list loop, with single-precision tolerances."""
+    # (a) one evaluation on a liquid box: forces, U_pot, virial against the FP64 list pass
+    L, ids, r, v = synth.bcc_box(20, temp=0.95, rho=0.6)  # (cells of a small box are coarse: at rho 0.6 every brick's shell is staged)
+    res = {}
+    for prec in (0, precision):
+        e = _engine(_lj(), 2.5, [L] * 3, ids, r, v, skin=0.25, precision=prec)
+        e.update()
+        assert e.get_option("precision_in_use") == prec
+        res[prec] = (e.forces_list(0, 0.0, want_macro=True), _state(e)[3])
+        e.close()
+    (u0, w0), F0 = res[0]
+    (u1, w1), F1 = res[precision]
+    assert rel_max(F1, F0) < tol_f and abs(u1 - u0) <= tol_f * abs(u0) and abs(w1 - w0) <= 10 * tol_f * abs(w0)
+    # (b) 20 fused steps (two list lifetimes) against the FP64 loop — whose trajectories the golden tests above pin to the real
+    # reference.  (The reference's own golden boxes are too small for this mode: their coarse cells overflow the staging area,
+    # which switches it off, see (c).)
+    runs = {}
+    for prec in (0, precision):
+        e = _engine(_lj(), 2.5, [L] * 3, ids, r, v, skin=0.25, precision=prec)
+        out = e.run(0.002, 20)
+        assert e.get_option("precision_in_use") == prec and e.get_option("verlet_steps") == 20 and e.get_option("verlet_builds") >= 2
+        runs[prec] = (out,) + _state(e)
+        e.close()
+    a, b = runs[0], runs[precision]
+    assert np.array_equal(a[1], b[1])
+    dr = a[2] - b[2]
+    dr -= L * np.round(dr / L)
+    assert np.max(np.abs(dr)) < tol_traj * L
+    assert rel_max(b[3], a[3]) < 20 * tol_traj and rel_max(b[4], a[4]) < 50 * tol_traj
+    for k in ("upot", "virial", "summv2"):
+        assert abs(a[0][k] - b[0][k]) <= 10 * tol_traj * abs(a[0][k]), k
+    # (c) irregular bricks (the dense blob of test_verlet_dense_cluster_fallbacks: list overflow, shells beyond the staging
+    # area) switch the mode off by themselves — the FP64 kernels run, with their FP64 results
+    rng = np.random.default_rng(5)
+    Lc = 40.0
+    gl = np.arange(14.0, 26.0, 0.55)
+    blob = np.stack(np.meshgrid(gl, gl, gl, indexing="ij"), -1).reshape(-1, 3) + rng.uniform(-0.1, 0.1, (len(gl) ** 3, 3))
+    hl = np.arange(1.0, Lc, 2.0)
+    rest = np.stack(np.meshgrid(hl, hl, hl, indexing="ij"), -1).reshape(-1, 3) + rng.uniform(-0.3, 0.3, (len(hl) ** 3, 3))
+    rest = rest[~np.all((rest > 13.0) & (rest < 27.0), axis=1)]
+    pts = np.concatenate([blob, rest])
+    idc = np.arange(1, len(pts) + 1, dtype=np.uint64)
+    soft = inp.ComponentSet([inp.make_component(lj=[(0, 0, 0, 1, 1e-3, 0.3, 2.5, 0)])], np.zeros((0, 2)), 1e10)
+    res = {}
+    for prec in (0, precision):
+        e = _engine(soft, 2.5, [Lc] * 3, idc, pts, np.zeros_like(pts), skin=0.3, precision=prec)
+        e.update()
+        assert e.get_option("precision") == prec and e.get_option("precision_in_use") == 0
+        e.forces_list(0, 0.0)
+        res[prec] = _state(e)[3]
+        e.close()
+    assert np.array_equal(res[0], res[precision])

@@ -1606,12 +1606,9 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 		} else if (c->thermostat_on) {
 			// NVT: the scaling factors depend on the kinetic sums after the kick, so the two half kicks stay separate
 			// passes: kick (+ sums, betas on the device) -> scale -> kick+drift   (Simulation.cpp:1099-1131)
+			// (the scaling itself is folded into the kick + drift pass, with the betas the kick's reduction left on the device)
 			if ((rc = ls1hip_kick(c, 0.5 * dt, nullptr, nullptr, nullptr, nullptr))) return rc;
-			{
-				TimedScope ts(c, c->t_integrate);
-				launch_scale(integ_args(c, 0.), 1., 1., true, c->stream);
-			}
-			if ((rc = ls1hip_kick_drift(c, dt))) return rc;
+			if ((rc = kick_drift_impl(c, dt, 2, 1., 1.))) return rc;
 		} else {
 			// post-force kick of step s-1 fused with the pre-force kick+drift of step s (same F, one pass)
 			if ((rc = ls1hip_kick_then_kick_drift(c, dt))) return rc;

@@ -883,6 +883,7 @@ static int before_force_pass(ls1hip_ctx* c, int which) {
 struct ForcePass {
 	int which = 0;
 	bool fuse = false;
+	bool post_kick = false;  // list mode: the pass does the post-force kick (+ sum m v^2) itself and keeps F (fuse must be false)
 	double dt = 0.;
 	int vl = 0;
 	bool lists_rebuilt = false;  // list mode: the lists were rebuilt in this step (the displacement bound restarts)
@@ -922,8 +923,8 @@ static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
 	ForceParams P;
 	fill_force_params(c, P, which);
 	const MolSoA& m = c->mol[c->cur];
-	if (fuse) {
-		P.fuse = 1;
+	if (fuse || fp.post_kick) {
+		P.fuse = fuse ? 1 : 2;
 		P.dt = fp.dt;
 		P.dt_inv2m = (.5 * fp.dt) / c->h_ct.mass[0];  // as k_kick_then_kick_drift: dt_halve / mass
 		P.mass = c->h_ct.mass[0];
@@ -984,7 +985,8 @@ static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
 	}
 	ReduceMode rm;
 	rm.overwrite = first_pass && !c->opt_count_pairs;
-	rm.kin_in_slot1 = fuse;
+	rm.kin_in_slot1 = fuse || fp.post_kick;
+	rm.target_T = (fp.post_kick && c->thermostat_on) ? c->thermostat_T : 0.;
 	rm.log = c->log_row;
 	if (fp.vl && fuse) {
 		rm.vmax_in_slot2 = true;
@@ -1492,13 +1494,20 @@ extern "C" int ls1hip_halo_refresh(ls1hip_ctx* c) {
 	return LS1HIP_OK;
 }
 
+static int forces_list_impl(ls1hip_ctx* c, int which, double dt, bool post_kick, double* upot, double* virial);
 extern "C" int ls1hip_forces_list(ls1hip_ctx* c, int which, double dt, double* upot, double* virial) {
+	return forces_list_impl(c, which, dt, false, upot, virial);
+}
+// post_kick (internal, ls1hip_run): dt is the time step, the pass is NOT fused with the drift but does the post-force kick and
+// the kinetic sum of the step itself (F is stored); which must be 0
+static int forces_list_impl(ls1hip_ctx* c, int which, double dt, bool post_kick, double* upot, double* virial) {
 	if (!c) return LS1HIP_EINVAL;
 	REQUIRE(c, which >= 0 && which <= 2, "which must be 0, 1 or 2");
 	REQUIRE(c, c->vl_ready, "no neighbour lists (ls1hip_verlet_build)");
 	REQUIRE(c, which == 1 || c->halo_valid, "halo positions are not current (ls1hip_halo_refresh / import_done(2))");
 	REQUIRE(c, dt >= 0., "dt must be >= 0 (0: forces only, > 0: fused with kick + kick + drift)");
-	const bool fuse = dt > 0.;
+	const bool fuse = dt > 0. && !post_kick;
+	REQUIRE(c, !post_kick || which == 0, "the post-force kick is folded into complete traversals only");
 	REQUIRE(c, !fuse || can_fuse(c), "fused list passes: no per-molecule virial, no device thermostat");
 	REQUIRE(c, (fuse && which == 2) ? c->fused_split == 1 : c->fused_split == 0,
 			"fused list passes must be which=0, or which=1 followed by which=2");
@@ -1512,6 +1521,7 @@ extern "C" int ls1hip_forces_list(ls1hip_ctx* c, int which, double dt, double* u
 		fp.fuse = fuse;
 		fp.dt = dt;
 		fp.vl = 2;
+		fp.post_kick = post_kick;
 		fp.lists_rebuilt = c->vl_fresh;
 		if ((rc = launch_forces(c, fp))) return rc;
 	}
@@ -1607,8 +1617,11 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 			// NVT: the scaling factors depend on the kinetic sums after the kick, so the two half kicks stay separate
 			// passes: kick (+ sums, betas on the device) -> scale -> kick+drift   (Simulation.cpp:1099-1131)
 			// (the scaling itself is folded into the kick + drift pass, with the betas the kick's reduction left on the device)
-			if ((rc = ls1hip_kick(c, 0.5 * dt, nullptr, nullptr, nullptr, nullptr))) return rc;
+			// In list mode the force pass of step s-1 has done the post-force kick and the kinetic sum (betas on the device).
+			if (!verlet && (rc = ls1hip_kick(c, 0.5 * dt, nullptr, nullptr, nullptr, nullptr))) return rc;
 			if ((rc = kick_drift_impl(c, dt, 2, 1., 1.))) return rc;
+		} else if (verlet) {
+			if ((rc = ls1hip_kick_drift(c, dt))) return rc;  // (post-force kick already done by the list force pass)
 		} else {
 			// post-force kick of step s-1 fused with the pre-force kick+drift of step s (same F, one pass)
 			if ((rc = ls1hip_kick_then_kick_drift(c, dt))) return rc;
@@ -1618,7 +1631,8 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 			// the lists, the binning and the halo slots live until the displacement bound of the molecules (accumulated on
 			// the device by whichever pass drifts them) exceeds skin / 2; then re-bin, regenerate the halo, rebuild the lists
 			if ((rc = ls1hip_update(c, nullptr))) return rc;
-			rc = ls1hip_forces_list(c, 0, advanced ? dt : 0., nullptr, nullptr);
+			// unfused steps (the last one; every step of an NVT run): the pass still does the post-force kick + sum m v^2
+			rc = advanced ? ls1hip_forces_list(c, 0, dt, nullptr, nullptr) : forces_list_impl(c, 0, dt, true, nullptr, nullptr);
 		} else if (c->opt_overlap_halo == 2) {
 			if ((rc = ls1hip_rebin(c))) return rc;
 			// halo first, then the inner and the boundary cells as two passes of the same stream
@@ -1641,7 +1655,7 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 		if (rc) return rc;
 		if (s + 1 == nsteps) {
 			c->log_row_kin = c->log_row;
-			if ((rc = ls1hip_kick(c, 0.5 * dt, nullptr, nullptr, nullptr, nullptr))) return rc;
+			if (!verlet && (rc = ls1hip_kick(c, 0.5 * dt, nullptr, nullptr, nullptr, nullptr))) return rc;
 			if (c->thermostat_on) {
 				TimedScope ts(c, c->t_integrate);
 				launch_scale(integ_args(c, 0.), 1., 1., true, c->stream);

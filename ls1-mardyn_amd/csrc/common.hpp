@@ -337,6 +337,7 @@ bool launch_force_sites(const ForceParams& p, const CompTable& hct, bool with_vi
 struct ReduceMode {
 	bool overwrite = false;     // first pass of a traversal: the sums start here
 	bool kin_in_slot1 = false;  // slot 1 = sum m v^2 of a fused pass
+	double target_T = 0.;       // ... and, if > 0, the thermostat factors are derived from it (Domain.cpp:225-240)
 	double* log = nullptr;      // step-log row to refresh
 	// list-reuse mode: slot 2 = max |v_drift|^2 (combined by max).  On the LAST pass of a step the displacement bound is
 	// advanced by dt * sqrt(vmax2) (after being reset when the lists were rebuilt in this step) and the rebuild flag

@@ -307,6 +307,7 @@ struct Reduce2Args {
 	uint32_t seq;
 	volatile uint32_t* flag;
 	double* log;
+	double target_T;
 };
 __global__ void __launch_bounds__(RED_BLOCKS) k_force_reduce2(DevCounters* cnt, const double* stage, Reduce2Args m) {
 	double v[4];
@@ -330,6 +331,10 @@ __global__ void __launch_bounds__(RED_BLOCKS) k_force_reduce2(DevCounters* cnt, 
 			cnt->kin_n = cnt->n_real;
 			cnt->kin_rotdof = 0;
 			s[1] = 0.;
+			if (m.target_T > 0. && cnt->kin_n > 0) {  // thermostat 0 of Domain::calculateGlobalValues, as k_kin_reduce
+				cnt->beta[0] = pow(3.0 * (double)cnt->kin_n * m.target_T / cnt->kin[0], 0.4);
+				cnt->beta[1] = 1.0;
+			}
 		}
 		if (m.vmax_in_slot2) {
 			cnt->vmax2 = m.overwrite ? s[2] : fmax(cnt->vmax2, s[2]);
@@ -370,6 +375,7 @@ void launch_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblo
 	Reduce2Args a;
 	a.overwrite = m.overwrite; a.kin_in_slot1 = m.kin_in_slot1; a.vmax_in_slot2 = m.vmax_in_slot2; a.last_pass = m.last_pass;
 	a.lists_rebuilt = m.lists_rebuilt; a.dt = m.dt; a.limit = m.limit; a.seq = m.seq; a.flag = m.flag; a.log = m.log;
+	a.target_T = m.target_T;
 	hipLaunchKernelGGL(k_force_reduce1, dim3(RED_BLOCKS), dim3(256), 0, s, partials, nblocks, stage, m.vmax_in_slot2 ? 1 : 0);
 	hipLaunchKernelGGL(k_force_reduce2, dim3(1), dim3(RED_BLOCKS), 0, s, cnt, stage, a);
 }

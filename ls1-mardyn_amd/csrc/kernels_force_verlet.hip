@@ -272,6 +272,18 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 				P.Fx[gi] = fx;
 				P.Fy[gi] = fy;
 				P.Fz[gi] = fz;
+			} else if (P.fuse == 2) {
+				// post-force kick only (upd_postF + sum m v^2, Leapfrog.cpp:66-150): F is kept for the pre-force kick of the
+				// next step, which has to wait for the thermostat's scaling factor (NVT) — saves the separate kick pass
+				const double k = P.dt_inv2m;
+				const double vx = vx0 + k * fx, vy = vy0 + k * fy, vz = vz0 + k * fz;
+				tot.kin += P.mass * (vx * vx + vy * vy + vz * vz);
+				P.vx[gi] = vx;
+				P.vy[gi] = vy;
+				P.vz[gi] = vz;
+				P.Fx[gi] = fx;
+				P.Fy[gi] = fy;
+				P.Fz[gi] = fz;
 			} else {
 				// lj_store of kernels_force_lj.hip (upd_postF, then upd_preF of the next step) + the drift speed of this step
 				const double k = P.dt_inv2m;
@@ -823,6 +835,16 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet_sp(ForceParams P, in
 			}
 			const double fxd = eps24 * dfx, fyd = eps24 * dfy, fzd = eps24 * dfz;
 			if (!P.fuse) {
+				P.Fx[gi] = fxd;
+				P.Fy[gi] = fyd;
+				P.Fz[gi] = fzd;
+			} else if (P.fuse == 2) {  // post-force kick only, F kept (see brick_forces)
+				const double k2 = P.dt_inv2m;
+				const double vx = vx0 + k2 * fxd, vy = vy0 + k2 * fyd, vz = vz0 + k2 * fzd;
+				tot.kin += P.mass * (vx * vx + vy * vy + vz * vz);
+				P.vx[gi] = vx;
+				P.vy[gi] = vy;
+				P.vz[gi] = vz;
 				P.Fx[gi] = fxd;
 				P.Fy[gi] = fyd;
 				P.Fz[gi] = fzd;

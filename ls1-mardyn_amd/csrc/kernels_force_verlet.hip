@@ -370,21 +370,38 @@ __device__ __forceinline__ void block_tables(const ForceParams& P, const BrickSe
 // Staging: 16 lanes per region cell, 32 cells per round.  ALL global loads of a thread (up to 5 cells x 2 molecules x 3
 // coordinates) are issued before the first LDS store waits for one: issued round by round the staging is a chain of ~5
 // L2 / HBM latencies per workgroup.
-__device__ __forceinline__ void stage_positions(const ForceParams& P, const BrickTab& T, double* sx, double* sy, double* sz) {
+// `after_issue` runs between the issue of the position loads and their LDS stores: loads requested there complete BEHIND the
+// positions (vmcnt retires in order), i.e. they do not hold up the staging and still have the stores and the barrier to arrive.
+struct NoOp {
+	__device__ void operator()() const {}
+};
+template <class F = NoOp>
+__device__ __forceinline__ void stage_positions(const ForceParams& P, const BrickTab& T, double* sx, double* sy, double* sz,
+												F after_issue = F()) {
 	constexpr int NR = (VNRC + VNT / 16 - 1) / (VNT / 16);  // rounds of cells per 16-lane group
 	const int tid = threadIdx.x;
 	const uint32_t sub = (uint32_t)tid & 15u, total = T.cstart[VNRC];
 	double px[NR][2], py[NR][2], pz[NR][2];
 	uint32_t sdst[NR][2];
 	bool more = false;
+	// every cell descriptor of the thread first (with the table in global memory — the build's record — they are one round of
+	// loads; fetched round by round, each round's descriptors waited behind the previous round's positions: vmcnt is in order)
+	uint32_t ds0[NR], dse[NR], dg0[NR];
+#pragma unroll
+	for (int j = 0; j < NR; ++j) {
+		const int c = min((tid >> 4) + j * (VNT / 16), VNRC - 1);
+		ds0[j] = T.cstart[c];
+		dse[j] = T.cstart[c + 1];
+		dg0[j] = T.gbeg[c];
+	}
 #pragma unroll
 	for (int j = 0; j < NR; ++j) {
 		const int c = (tid >> 4) + j * (VNT / 16);
 		uint32_t n = 0, s0 = 0, g0 = 0;
 		if (c < VNRC) {
-			s0 = T.cstart[c];
-			n = T.cstart[c + 1] - s0;
-			g0 = T.gbeg[c];
+			s0 = ds0[j];
+			n = dse[j] - s0;
+			g0 = dg0[j];
 		}
 		more |= n > 32u;
 #pragma unroll
@@ -398,6 +415,7 @@ __device__ __forceinline__ void stage_positions(const ForceParams& P, const Bric
 			pz[j][h] = P.z[g];
 		}
 	}
+	after_issue();
 #pragma unroll
 	for (int j = 0; j < NR; ++j)
 #pragma unroll
@@ -456,10 +474,9 @@ __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int n
 	const uint32_t total = cstart[VNRC], n_i = bstart[NBC];
 	uint32_t* const rec = P.vl_rec + (size_t)bs.id * VREC;
 	if (total > (uint32_t)VCAPJ) {  // unstaged brick: evaluated directly every step, no lists
-		if (tid == 0) {
-			rec[VREC_FLAGS] = 0;
-			atomicAdd(&P.cnt->vl_irregular, 1u);
-		}
+		// an empty record: the force pass stages from the record BEFORE it looks at the flags (nothing to stage here)
+		for (int c = tid; c < VREC; c += NT) rec[c] = 0;
+		if (tid == 0) atomicAdd(&P.cnt->vl_irregular, 1u);
 		return;
 	}
 	// the brick's record: what the force pass would otherwise recompute every step (cell loads, two scans, six barriers)
@@ -619,24 +636,33 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet(ForceParams P, int n
 		if (tid < 4) P.partials[(size_t)blockIdx.x * 4 + tid] = 0.;
 		return;
 	}
-	const ListHead head = load_list_head(P, bs.id, wv, lane);  // independent of everything staged below: issued first
+	ListHead head;
 	Totals tot = {0., 0., 0., 0.};
 	uint32_t* const rec = P.vl_rec + (size_t)bs.id * VREC;
 	// own LDS slot / global index of the first pass, issued together with the list head and the flags (reads of valid memory
 	// whatever the flags say): nothing the pair loop needs is requested after the staging barrier
 	const uint16_t* const f_ii = P.vl_ii + (size_t)bs.id * (VMAXT * 64);
 	const uint32_t* const f_gi = P.vl_gi + (size_t)bs.id * (VMAXT * 64);
-	const uint32_t ii0 = f_ii[tid], gi0 = f_gi[tid];
-	if (rec[VREC_FLAGS] & 1u) {  // uniform per workgroup
-		// regular brick (staged, every tile has its list): cell table and own indices come from the build's record — no cell
-		// loads, no scans, no table search; the only barrier of the workgroup is the one behind the staging
+	uint32_t ii0 = 0, gi0 = 0;
+	// Staging straight from the build's record, BEFORE the flags are looked at: the descriptor loads leave first, ahead of the
+	// list head and the own indices, instead of behind a dependent flag load (an unstaged brick has an empty record).
+	// (Also requesting list rows 2 and 3 up here was measured: slower — vmcnt completes in order, so the staging then waits for
+	// two more HBM round trips.)
+	{
 		const BrickTab R = {rec, rec + VREC_GBEG, nullptr};
+		head = load_list_head(P, bs.id, wv, lane);  // list head and own indices: independent of everything staged below
+		ii0 = f_ii[tid];
+		gi0 = f_gi[tid];
 		stage_positions(P, R, sx, sy, sz);
 		if (tid == 0) {
 			cstart[VNRC] = rec[VNRC];
 			bstart[VNBC] = rec[VREC_NI];
 		}
-		__syncthreads();
+	}
+	__syncthreads();
+	if (rec[VREC_FLAGS] & 1u) {  // uniform per workgroup
+		// regular brick (staged, every tile has its list): cell table and own indices come from the build's record — no cell
+		// loads, no scans, no table search; the only barrier of the workgroup is the one behind the staging
 		const BrickTab T = {cstart, gbeg, bstart};  // (only the two totals are read on this path)
 		brick_forces<SHIFT>(P, T, sx, sy, sz, bs.id, true, head, tot, f_ii, f_gi, ii0, gi0);
 	} else {

@@ -490,12 +490,58 @@ __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int n
 	const double ox = P.g.bmin[0] + (double)(bs.x0 - 2) * P.g.clen[0];
 	const double oy = P.g.bmin[1] + (double)(bs.y0 - 2) * P.g.clen[1];
 	const double oz = P.g.bmin[2] + (double)(bs.z0 - 2) * P.g.clen[2];
-	for (int c = tid >> 4; c < VNRC; c += NT / 16) {
-		const uint32_t n = cstart[c + 1] - cstart[c], s0 = cstart[c], g0 = gbeg[c];
-		for (uint32_t k = (uint32_t)tid & 15u; k < n; k += 16u) {
-			fx[s0 + k] = (float)(P.x[g0 + k] - ox);
-			fy[s0 + k] = (float)(P.y[g0 + k] - oy);
-			fz[s0 + k] = (float)(P.z[g0 + k] - oz);
+	{
+		// 16 lanes per region cell, 32 cells per round; the global loads of a thread are issued in two batches (three + two
+		// rounds) before their conversions wait for them — round by round the staging was a chain of five HBM latencies per
+		// workgroup; all five rounds at once cost 30 more VGPRs and the third workgroup per CU
+		constexpr int NR = (VNRC + NT / 16 - 1) / (NT / 16);
+		constexpr int NB = 3;
+		const uint32_t sub = (uint32_t)tid & 15u;
+		bool more = false;
+#pragma unroll
+		for (int j0 = 0; j0 < NR; j0 += NB) {
+			double px[NB][2], py[NB][2], pz[NB][2];
+			uint32_t sdst[NB][2];
+#pragma unroll
+			for (int jj = 0; jj < NB; ++jj) {
+				const int c = (tid >> 4) + (j0 + jj) * (NT / 16);
+				uint32_t n = 0, s0 = 0, g0 = 0;
+				if (j0 + jj < NR && c < VNRC) {
+					s0 = cstart[c];
+					n = cstart[c + 1] - s0;
+					g0 = gbeg[c];
+				}
+				more |= n > 32u;
+#pragma unroll
+				for (int h = 0; h < 2; ++h) {
+					const uint32_t k = sub + 16u * h;
+					const bool ok = k < n;
+					sdst[jj][h] = ok ? s0 + k : 0xffffffffu;
+					const uint32_t g = ok ? g0 + k : 0u;
+					px[jj][h] = P.x[g];
+					py[jj][h] = P.y[g];
+					pz[jj][h] = P.z[g];
+				}
+			}
+#pragma unroll
+			for (int jj = 0; jj < NB; ++jj)
+#pragma unroll
+				for (int h = 0; h < 2; ++h)
+					if (sdst[jj][h] != 0xffffffffu) {
+						fx[sdst[jj][h]] = (float)(px[jj][h] - ox);
+						fy[sdst[jj][h]] = (float)(py[jj][h] - oy);
+						fz[sdst[jj][h]] = (float)(pz[jj][h] - oz);
+					}
+		}
+		if (more) {  // cells with more than 32 molecules: the rest in a plain loop
+			for (int c = tid >> 4; c < VNRC; c += NT / 16) {
+				const uint32_t n = cstart[c + 1] - cstart[c], s0 = cstart[c], g0 = gbeg[c];
+				for (uint32_t k = 32u + sub; k < n; k += 16u) {
+					fx[s0 + k] = (float)(P.x[g0 + k] - ox);
+					fy[s0 + k] = (float)(P.y[g0 + k] - oy);
+					fz[s0 + k] = (float)(P.z[g0 + k] - oz);
+				}
+			}
 		}
 	}
 	if (tid < 8) {
@@ -737,14 +783,22 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet_sp(ForceParams P, in
 		double px[NR][2], py[NR][2], pz[NR][2];
 		uint32_t sdst[NR][2];
 		bool more = false;
+		uint32_t ds0[NR], dse[NR], dg0[NR];  // every descriptor first: one round of loads (see stage_positions)
+#pragma unroll
+		for (int j = 0; j < NR; ++j) {
+			const int c = min((tid >> 4) + j * (NT / 16), VNRC - 1);
+			ds0[j] = rec[c];
+			dse[j] = rec[c + 1];
+			dg0[j] = rec[VREC_GBEG + c];
+		}
 #pragma unroll
 		for (int j = 0; j < NR; ++j) {
 			const int c = (tid >> 4) + j * (NT / 16);
 			uint32_t n = 0, s0 = 0, g0 = 0;
 			if (c < VNRC) {
-				s0 = rec[c];
-				n = rec[c + 1] - s0;
-				g0 = rec[VREC_GBEG + c];
+				s0 = ds0[j];
+				n = dse[j] - s0;
+				g0 = dg0[j];
 			}
 			more |= n > 32u;
 #pragma unroll

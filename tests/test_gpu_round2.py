@@ -315,3 +315,34 @@ def test_scale_kick_drift_is_bitwise_the_two_separate_passes():
             e.close()
         for k in ("r", "v", "q", "D"):
             assert np.array_equal(res[0][k], res[1][k]), (name, k)
+
+
+def test_queued_traversal_and_kick_give_the_synchronous_results():
+    """ls1hip_traversal_mark / _sums and ls1hip_kinetic_sums (the calls behind the seam-B overlap: traversal and post-force kick
+    queued back to back, the host waits for the traversal's sums only) == ls1hip_forces(&upot, &virial) followed by
+    ls1hip_kick(&sums), bit for bit."""
+    case = MAN["bcc1clj_3456_steps10"]
+    ps = inp.read_inp(input_path(case["input"]))
+    st = sorted_phase_space(ps)
+    res = []
+    for queued in (False, True):
+        e = engine_mod.DeviceEngine(0)
+        e.set_components(ps.components, case["rc"])
+        e.set_domain(ps.length)
+        e.upload(st["ids"], st["cid"], st["r"], st["v"])
+        e.rebin(); e.halo()
+        if queued:
+            e.forces(0, want_macro=False)
+            e.traversal_mark()
+            e.kick(0.5 * case["dt"], want_sums=False)
+            macro = e.traversal_sums()
+            kin = e.kinetic_sums()
+        else:
+            macro = e.forces(0, want_macro=True)
+            kin = e.kick(0.5 * case["dt"], want_sums=True)
+        s = e.download_state()
+        o = np.argsort(s["ids"], kind="stable")
+        res.append((macro, kin, s["v"][o]))
+        e.close()
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
+    assert np.array_equal(res[0][2], res[1][2])

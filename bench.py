@@ -195,6 +195,8 @@ def main():
     ap.add_argument("--precision", choices=("dp", "spdp", "spsp"), default="dp",
                     help="pair arithmetic of the list force pass: dp = FP64 (the metric's precision, default); spdp / spsp = the "
                          "reference's single-precision build modes (NOT the headline: dtype says so)")
+    ap.add_argument("--nvt", action="store_true", help="velocity-scaling thermostat on the device (as every shipped example of the "
+                                                        "reference; the headline metric is the NVE loop)")
     ap.add_argument("--no-fuse", action="store_true", help="separate integrator passes instead of the fused force pass")
     ap.add_argument("--decomp", action="store_true",
                     help="diagnostic: run the decomposed (multi-rank) step loop even with one rank")
@@ -286,6 +288,8 @@ def main():
         (sim.engine if sim is not None else eng).set_option("fuse_integration", 0)
     if args.overlap >= 0:
         (sim.engine if sim is not None else eng).set_option("overlap_halo", args.overlap)
+    if args.nvt:
+        (sim.engine if sim is not None else eng).set_thermostat(True, TEMP)
     if args.precision != "dp":
         (sim.engine if sim is not None else eng).set_option("precision", {"spdp": 1, "spsp": 2}[args.precision])
 
@@ -384,6 +388,8 @@ def main():
                                             "note": "lists, binning and halo slots reused until the device-side displacement "
                                                     "bound exceeds skin/2 (counts since start incl. warm-up and profiling steps)"}
                                            if e.get_option("verlet_lists") else None),
+                       "ensemble": ("NVT: velocity-scaling thermostat on the device, post-force kick + kinetic sum inside the force "
+                                    "pass, scaling folded into the kick + drift pass" if args.nvt else "NVE"),
                        "integration": ("fused into the force pass between steps (reduced-memory mode), last step separate"
                                        if fused_on else "separate integrator passes")},
             "roofline": {"bound": "hbm", "kernel": "pair-force traversal (k_force_*)", "achieved": achieved,

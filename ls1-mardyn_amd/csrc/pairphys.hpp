@@ -1,5 +1,8 @@
 // pairphys.hpp — site-site pair bodies for the MI355X force kernels (FP64).
 //
+// Notation: r = site-site vector, ir1 = 1/|r|, ir2 = 1/r^2, ca / cb = direction cosines of the two axes with r, cg = cosine between
+// the axes, w_* = radial prefactors, dUd*_over_r = partial derivatives of the pair energy divided by |r|.
+//
 // One-sided ("full shell") formulation: every function returns what molecule i receives from site j —
 // force f on i's site, torque m on i, pair energy u — so each lane owns its molecule's accumulators and no
 // atomics or cross-lane reductions are needed in the hot loop.  The physics is that of the reference's scalar
@@ -63,120 +66,120 @@ LS1_HD V3 rotate_inv(const Rot& R, V3 d) {
 // ---- LJ 12-6: potforce.h:18-30 / VectorizedCellProcessor::_loopBodyLJ (VectorizedCellProcessor.cpp:173-226).
 // dr = r_i - r_j (sites).  f = force on i.  u6 = 6*U (without shift).
 LS1_HD void lj(V3 dr, double dr2, double eps24, double sig2, V3& f, double& u6) {
-	const double invdr2 = 1. / dr2;
-	double lj6 = sig2 * invdr2;
+	const double ir2 = 1. / dr2;
+	double lj6 = sig2 * ir2;
 	lj6 = lj6 * lj6 * lj6;
 	const double lj12 = lj6 * lj6;
 	const double lj12m6 = lj12 - lj6;
 	u6 = eps24 * lj12m6;
-	const double fac = eps24 * (lj12 + lj12m6) * invdr2;
+	const double fac = eps24 * (lj12 + lj12m6) * ir2;
 	f = fac * dr;
 }
 
 // ---- charge-charge: potforce.h:190-199.
 LS1_HD void charge_charge(V3 dr, double dr2, double q1q2, V3& f, double& u) {
-	const double invdr2 = 1.0 / dr2;
-	const double invdr = sqrt(invdr2);
-	u = q1q2 * invdr;
-	f = (u * invdr2) * dr;
+	const double ir2 = 1.0 / dr2;
+	const double ir1 = sqrt(ir2);
+	u = q1q2 * ir1;
+	f = (u * ir2) * dr;
 }
 
 // ---- charge (site a) - dipole (site b): potforce.h:237-263.  dr = r_a - r_b, e = dipole axis,
-// mqmy = -q*my.  fa = force on the charge; mb = torque on the dipole.
-LS1_HD void charge_dipole(V3 dr, double dr2, V3 e, double mqmy, V3& fa, V3& mb, double& u) {
-	const double invdr2 = 1.0 / dr2;
-	const double invdr = sqrt(invdr2);
-	const double costj = dot(e, dr) * invdr;
-	const double uInvcostj = mqmy * invdr2;
-	u = uInvcostj * costj;
-	const double partialTjInvdr1 = uInvcostj * invdr;
-	const double fac = 3.0 * u * invdr2;
-	fa = fac * dr - partialTjInvdr1 * e;
-	mb = partialTjInvdr1 * cross(dr, e);
+// neg_q_my = -q*my.  fa = force on the charge; mb = torque on the dipole.
+LS1_HD void charge_dipole(V3 dr, double dr2, V3 e, double neg_q_my, V3& fa, V3& mb, double& u) {
+	const double ir2 = 1.0 / dr2;
+	const double ir1 = sqrt(ir2);
+	const double cb = dot(e, dr) * ir1;
+	const double k_cd = neg_q_my * ir2;
+	u = k_cd * cb;
+	const double dUdb_over_r = k_cd * ir1;
+	const double fac = 3.0 * u * ir2;
+	fa = fac * dr - dUdb_over_r * e;
+	mb = dUdb_over_r * cross(dr, e);
 }
 
-// ---- charge (a) - quadrupole (b): potforce.h:205-231.  qQ05 = 0.5*q*Q.
-LS1_HD void charge_quadrupole(V3 dr, double dr2, V3 e, double qQ05, V3& fa, V3& mb, double& u) {
-	const double invdr2 = 1.0 / dr2;
-	const double invdr = sqrt(invdr2);
-	const double costj = dot(e, dr) * invdr;
-	const double qQinv4dr3 = qQ05 * invdr * invdr2;
-	u = qQinv4dr3 * (3.0 * costj * costj - 1);
-	const double partialRijInvdr1 = -3.0 * u * invdr2;
-	const double partialTjInvdr1 = 6.0 * costj * qQinv4dr3 * invdr;
-	const double fac = costj * partialTjInvdr1 * invdr - partialRijInvdr1;
-	fa = fac * dr - partialTjInvdr1 * e;
-	mb = partialTjInvdr1 * cross(dr, e);
+// ---- charge (a) - quadrupole (b): potforce.h:205-231.  half_qQ = 0.5*q*Q.
+LS1_HD void charge_quadrupole(V3 dr, double dr2, V3 e, double half_qQ, V3& fa, V3& mb, double& u) {
+	const double ir2 = 1.0 / dr2;
+	const double ir1 = sqrt(ir2);
+	const double cb = dot(e, dr) * ir1;
+	const double w_cq = half_qQ * ir1 * ir2;
+	u = w_cq * (3.0 * cb * cb - 1);
+	const double dUdr_over_r = -3.0 * u * ir2;
+	const double dUdb_over_r = 6.0 * cb * w_cq * ir1;
+	const double fac = cb * dUdb_over_r * ir1 - dUdr_over_r;
+	fa = fac * dr - dUdb_over_r * e;
+	mb = dUdb_over_r * cross(dr, e);
 }
 
 // ---- dipole (i) - dipole (j): potforce.h:36-80.  dr = r_i - r_j.  f = force on i, mi / mj torques,
 // rf = reaction-field energy contribution of the pair (MyRF -= rffac*cos gamma).
 LS1_HD void dipole_dipole(V3 dr, double dr2, V3 ei, V3 ej, double my2, double rffac, V3& f, V3& mi, V3& mj, double& u,
 						  double& rf) {
-	const double invdr2 = 1. / dr2;
-	const double invdr1 = sqrt(invdr2);
-	const double myfac = my2 * invdr2 * invdr1;
-	double costi = dot(ei, dr), costj = dot(ej, dr);
-	const double cosgij = dot(ei, ej);
-	costi *= invdr1;
-	costj *= invdr1;
-	u = myfac * (cosgij - 3. * costi * costj);
-	rf = -rffac * cosgij;
-	const double partialRijInvdr1 = -3. * u * invdr2;
-	const double partialTiInvdr1 = -myfac * 3. * costj * invdr1;
-	const double partialTjInvdr1 = -myfac * 3. * costi * invdr1;
-	const double partialGij = myfac;
-	const double fac = -partialRijInvdr1 + (costi * partialTiInvdr1 + costj * partialTjInvdr1) * invdr1;
-	f = fac * dr - partialTiInvdr1 * ei - partialTjInvdr1 * ej;
-	const V3 eiXej = cross(ei, ej);
-	mi = (-partialTiInvdr1) * cross(ei, dr) + (-partialGij + rffac) * eiXej;
-	mj = (-partialTjInvdr1) * cross(ej, dr) + (partialGij - rffac) * eiXej;
+	const double ir2 = 1. / dr2;
+	const double ir1 = sqrt(ir2);
+	const double w_dd = my2 * ir2 * ir1;
+	double ca = dot(ei, dr), cb = dot(ej, dr);
+	const double cg = dot(ei, ej);
+	ca *= ir1;
+	cb *= ir1;
+	u = w_dd * (cg - 3. * ca * cb);
+	rf = -rffac * cg;
+	const double dUdr_over_r = -3. * u * ir2;
+	const double dUda_over_r = -w_dd * 3. * cb * ir1;
+	const double dUdb_over_r = -w_dd * 3. * ca * ir1;
+	const double dUdg = w_dd;
+	const double fac = -dUdr_over_r + (ca * dUda_over_r + cb * dUdb_over_r) * ir1;
+	f = fac * dr - dUda_over_r * ei - dUdb_over_r * ej;
+	const V3 ea_x_eb = cross(ei, ej);
+	mi = (-dUda_over_r) * cross(ei, dr) + (-dUdg + rffac) * ea_x_eb;
+	mj = (-dUdb_over_r) * cross(ej, dr) + (dUdg - rffac) * ea_x_eb;
 }
 
-// ---- quadrupole (i) - quadrupole (j): potforce.h:86-133.  q2075 = 0.75*Qi*Qj.
-LS1_HD void quadrupole_quadrupole(V3 dr, double dr2, V3 ei, V3 ej, double q2075, V3& f, V3& mi, V3& mj, double& u) {
-	const double invdr2 = 1. / dr2;
-	const double invdr1 = sqrt(invdr2);
-	const double qfac = q2075 * invdr2 * invdr2 * invdr1;
-	double costi = dot(ei, dr), costj = dot(ej, dr);
-	const double cosgij = dot(ei, ej);
-	costi *= invdr1;
-	costj *= invdr1;
-	const double cos2ti = costi * costi, cos2tj = costj * costj;
-	const double term = (cosgij - 5. * costi * costj);
-	u = qfac * (1. - 5. * (cos2ti + cos2tj) - 15. * cos2ti * cos2tj + 2. * term * term);
-	const double partialRijInvdr1 = -5. * u * invdr2;
-	const double partialTiInvdr1 = -qfac * 10. * (costi + 3. * costi * cos2tj + 2. * costj * term) * invdr1;
-	const double partialTjInvdr1 = -qfac * 10. * (costj + 3. * cos2ti * costj + 2. * costi * term) * invdr1;
-	const double partialGij = qfac * 4. * term;
-	const double fac = -partialRijInvdr1 + (costi * partialTiInvdr1 + costj * partialTjInvdr1) * invdr1;
-	f = fac * dr - partialTiInvdr1 * ei - partialTjInvdr1 * ej;
-	const V3 eiXej = cross(ei, ej);
-	mi = (-partialTiInvdr1) * cross(ei, dr) - partialGij * eiXej;
-	mj = (-partialTjInvdr1) * cross(ej, dr) + partialGij * eiXej;
+// ---- quadrupole (i) - quadrupole (j): potforce.h:86-133.  qq075 = 0.75*Qi*Qj.
+LS1_HD void quadrupole_quadrupole(V3 dr, double dr2, V3 ei, V3 ej, double qq075, V3& f, V3& mi, V3& mj, double& u) {
+	const double ir2 = 1. / dr2;
+	const double ir1 = sqrt(ir2);
+	const double w_qq = qq075 * ir2 * ir2 * ir1;
+	double ca = dot(ei, dr), cb = dot(ej, dr);
+	const double cg = dot(ei, ej);
+	ca *= ir1;
+	cb *= ir1;
+	const double ca2 = ca * ca, cb2 = cb * cb;
+	const double term = (cg - 5. * ca * cb);
+	u = w_qq * (1. - 5. * (ca2 + cb2) - 15. * ca2 * cb2 + 2. * term * term);
+	const double dUdr_over_r = -5. * u * ir2;
+	const double dUda_over_r = -w_qq * 10. * (ca + 3. * ca * cb2 + 2. * cb * term) * ir1;
+	const double dUdb_over_r = -w_qq * 10. * (cb + 3. * ca2 * cb + 2. * ca * term) * ir1;
+	const double dUdg = w_qq * 4. * term;
+	const double fac = -dUdr_over_r + (ca * dUda_over_r + cb * dUdb_over_r) * ir1;
+	f = fac * dr - dUda_over_r * ei - dUdb_over_r * ej;
+	const V3 ea_x_eb = cross(ei, ej);
+	mi = (-dUda_over_r) * cross(ei, dr) - dUdg * ea_x_eb;
+	mj = (-dUdb_over_r) * cross(ej, dr) + dUdg * ea_x_eb;
 }
 
-// ---- dipole (a) - quadrupole (b): potforce.h:139-184.  dr = r_a - r_b.  myq15 = 1.5*my*Q.
+// ---- dipole (a) - quadrupole (b): potforce.h:139-184.  dr = r_a - r_b.  dq15 = 1.5*my*Q.
 // f = force on the dipole site, ma / mb torques on dipole / quadrupole.
-LS1_HD void dipole_quadrupole(V3 dr, double dr2, V3 ea, V3 eb, double myq15, V3& f, V3& ma, V3& mb, double& u) {
-	const double invdr2 = 1. / dr2;
-	const double invdr1 = sqrt(invdr2);
-	const double myqfac = myq15 * invdr2 * invdr2;
-	double costi = dot(ea, dr), costj = dot(eb, dr);
-	const double cosgij = dot(ea, eb);
-	costi *= invdr1;
-	costj *= invdr1;
-	const double cos2tj = costj * costj;
-	u = myqfac * (-costi * (5. * cos2tj - 1.) + 2. * cosgij * costj);
-	const double partialRijInvdr1 = -4. * u * invdr2;
-	const double partialTiInvdr1 = myqfac * (-5. * cos2tj + 1.) * invdr1;
-	const double partialTjInvdr1 = myqfac * 2. * (-5. * costi * costj + cosgij) * invdr1;
-	const double partialGij = myqfac * 2. * costj;
-	const double fac = -partialRijInvdr1 + (costi * partialTiInvdr1 + costj * partialTjInvdr1) * invdr1;
-	f = fac * dr - partialTiInvdr1 * ea - partialTjInvdr1 * eb;
-	const V3 eiXej = cross(ea, eb);
-	ma = (-partialTiInvdr1) * cross(ea, dr) - partialGij * eiXej;
-	mb = (-partialTjInvdr1) * cross(eb, dr) + partialGij * eiXej;
+LS1_HD void dipole_quadrupole(V3 dr, double dr2, V3 ea, V3 eb, double dq15, V3& f, V3& ma, V3& mb, double& u) {
+	const double ir2 = 1. / dr2;
+	const double ir1 = sqrt(ir2);
+	const double w_dq = dq15 * ir2 * ir2;
+	double ca = dot(ea, dr), cb = dot(eb, dr);
+	const double cg = dot(ea, eb);
+	ca *= ir1;
+	cb *= ir1;
+	const double cb2 = cb * cb;
+	u = w_dq * (-ca * (5. * cb2 - 1.) + 2. * cg * cb);
+	const double dUdr_over_r = -4. * u * ir2;
+	const double dUda_over_r = w_dq * (-5. * cb2 + 1.) * ir1;
+	const double dUdb_over_r = w_dq * 2. * (-5. * ca * cb + cg) * ir1;
+	const double dUdg = w_dq * 2. * cb;
+	const double fac = -dUdr_over_r + (ca * dUda_over_r + cb * dUdb_over_r) * ir1;
+	f = fac * dr - dUda_over_r * ea - dUdb_over_r * eb;
+	const V3 ea_x_eb = cross(ea, eb);
+	ma = (-dUda_over_r) * cross(ea, dr) - dUdg * ea_x_eb;
+	mb = (-dUdb_over_r) * cross(eb, dr) + dUdg * ea_x_eb;
 }
 
 }  // namespace ls1

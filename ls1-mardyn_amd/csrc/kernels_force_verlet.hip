@@ -447,7 +447,8 @@ __device__ __forceinline__ void stage_positions(const ForceParams& P, const Bric
 // so the search runs in FP32 on brick-relative coordinates with a conservative threshold: packed FP32 arithmetic handles
 // two candidates per instruction (v_pk_add / v_pk_mul / v_pk_fma_f32: 3 VALU per candidate instead of 6 FP64), the staged
 // region shrinks to 12 B per molecule (34 KB: the search kernel is not LDS-capacity bound) and its LDS reads halve.
-// Per candidate the bookkeeping is: compare, add-with-carry into the count, slot address (and-or), one ds_write_b16.
+// Per candidate the bookkeeping is a compare and an add-with-carry that shifts the outcome into a per-lane bit mask; list
+// entries are formed for the hits only (see the scan below).
 // FP32 slack: coordinates are relative to the region's low corner (< 6 cell lengths), |r^2_fp32 - r^2| <= 2 (|dx| + |dy| +
 // |dz|) ulp(extent) + 3 ulp(r^2) ~ 4e-5 at liquid-argon scale; the threshold adds 2e-6 * extent * (rc + skin) + 1e-5 (rc +
 // skin)^2, several times that bound.
@@ -456,15 +457,12 @@ typedef f32x2 f32x2_a4 __attribute__((aligned(4)));  // candidate pairs start at
 
 __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int nbx, int nby, int nbz) {
 	constexpr int NT = VNT, RX = VRX, RY = VRY, BX = VBX, BY = VBY, NBC = VNBC, CAPS = VCAPS;
-	__shared__ float fpos[3 * CAPS];
-	float* const fx = fpos;
-	float* const fy = fpos + CAPS;
-	float* const fz = fpos + 2 * CAPS;
+	__shared__ float fpos[3 * CAPS];  // x, y, z of a molecule side by side: a group of four candidates is 12 consecutive dwords,
+	                                  // read as six ds_read2_b32 (x0 x1 | y0 y1 | ...) off ONE address register
 	__shared__ uint32_t cstart[VNRC + 1];
 	__shared__ uint32_t gbeg[VNRC];
 	__shared__ uint32_t bstart[NBC + 1];
 	__shared__ uint32_t wsum[VNW];
-	__shared__ uint16_t win[8 * NT];  // per-lane window of two list words, slot-major
 	__shared__ uint32_t ovf;          // some tile of the brick has no stored list
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const BrickSel bs = brick_select<1, VBX, VBY, VBZ>(P, nbx, nby, nbz);
@@ -528,26 +526,26 @@ __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int n
 #pragma unroll
 				for (int h = 0; h < 2; ++h)
 					if (sdst[jj][h] != 0xffffffffu) {
-						fx[sdst[jj][h]] = (float)(px[jj][h] - ox);
-						fy[sdst[jj][h]] = (float)(py[jj][h] - oy);
-						fz[sdst[jj][h]] = (float)(pz[jj][h] - oz);
+						fpos[3 * sdst[jj][h]] = (float)(px[jj][h] - ox);
+						fpos[3 * sdst[jj][h] + 1] = (float)(py[jj][h] - oy);
+						fpos[3 * sdst[jj][h] + 2] = (float)(pz[jj][h] - oz);
 					}
 		}
 		if (more) {  // cells with more than 32 molecules: the rest in a plain loop
 			for (int c = tid >> 4; c < VNRC; c += NT / 16) {
 				const uint32_t n = cstart[c + 1] - cstart[c], s0 = cstart[c], g0 = gbeg[c];
 				for (uint32_t k = 32u + sub; k < n; k += 16u) {
-					fx[s0 + k] = (float)(P.x[g0 + k] - ox);
-					fy[s0 + k] = (float)(P.y[g0 + k] - oy);
-					fz[s0 + k] = (float)(P.z[g0 + k] - oz);
+					fpos[3 * (s0 + k)] = (float)(P.x[g0 + k] - ox);
+					fpos[3 * (s0 + k) + 1] = (float)(P.y[g0 + k] - oy);
+					fpos[3 * (s0 + k) + 2] = (float)(P.z[g0 + k] - oz);
 				}
 			}
 		}
 	}
 	if (tid < 8) {
-		fx[total + tid] = 1.0e18f;  // far-away padding behind the last molecule (r^2 ~ 1e36, finite)
-		fy[total + tid] = 1.0e18f;
-		fz[total + tid] = 1.0e18f;
+		fpos[3 * (total + tid)] = 1.0e18f;  // far-away padding behind the last molecule (r^2 ~ 1e36, finite)
+		fpos[3 * (total + tid) + 1] = 1.0e18f;
+		fpos[3 * (total + tid) + 2] = 1.0e18f;
 	}
 	__syncthreads();
 	const uint64_t dummy = (uint64_t)(total * 8u) * 0x0001000100010001ull;  // four entries pointing at the far-away slot
@@ -575,71 +573,89 @@ __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int n
 			const int rowbase = (cz * RY + cy) * RX + cx;
 			P.vl_ii[(size_t)bs.id * (VMAXT * 64) + it] = (uint16_t)ii;
 			P.vl_gi[(size_t)bs.id * (VMAXT * 64) + it] = gbeg[rcell] + (it - bstart[lo]);
-			const f32x2 xi = {fx[ii], fx[ii]}, yi = {fy[ii], fy[ii]}, zi = {fz[ii], fz[ii]};
-			const uint32_t wb = (uint32_t)tid * 2u;  // byte offset of this lane inside a window row (rows of ROWB = NT * 2 bytes)
-			constexpr uint32_t ROWB = (uint32_t)NT * 2u;
-			static_assert((ROWB & (ROWB - 1u)) == 0u, "the slot address is formed with an OR");
-			char* const winb = reinterpret_cast<char*>(win);
-			// one candidate: unconditional store of its offset at slot cnt & 7, cnt advances on a hit (a miss is overwritten)
-			auto put = [&](uint32_t j, bool hit) {
-				*reinterpret_cast<uint16_t*>(winb + (((cnt & 7u) * ROWB) | wb)) = (uint16_t)(j * 8u);  // (v_and + v_lshl_or)
-				cnt += hit ? 1u : 0u;
-			};
-			auto flush = [&](uint32_t before) {
-				if ((cnt >> 2) != (before >> 2)) {  // a word of four entries is complete
-					const uint32_t w = before >> 2;
-					const char* const s0 = winb + ((w & 1u) * (4u * ROWB) + wb);
-					const uint64_t e0 = *reinterpret_cast<const uint16_t*>(s0), e1 = *reinterpret_cast<const uint16_t*>(s0 + ROWB),
-								   e2 = *reinterpret_cast<const uint16_t*>(s0 + 2 * ROWB), e3 = *reinterpret_cast<const uint16_t*>(s0 + 3 * ROWB);
-					if (w < (uint32_t)VMAXW) wp[(size_t)w * 64] = e0 | (e1 << 16) | (e2 << 32) | (e3 << 48);
-				}
+			const f32x2 xi = {fpos[3 * ii], fpos[3 * ii]}, yi = {fpos[3 * ii + 1], fpos[3 * ii + 1]}, zi = {fpos[3 * ii + 2], fpos[3 * ii + 2]};
+			// Search in two phases per block of 32 candidates.  SCAN: distance test of every candidate, its outcome shifted into a
+			// per-lane bit mask by the compare's carry (v_cmp + v_addc: two instructions of bookkeeping per candidate; the first
+			// version stored every candidate into an LDS window and let misses be overwritten: five + one ds_write).  EXTRACT: only
+			// the hits (14 % of the candidates) are turned into list entries, highest bit first = ascending candidate order, and
+			// collected in a register pair that is stored as a word of four entries when full.
+			uint32_t wlo = 0, whi = 0;
+			const f32x2 nthr = {-thr, -thr};
+			auto put_hit = [&](uint32_t j8) {  // j8 = LDS byte offset of the neighbour's x (< 65536)
+				wlo = __builtin_amdgcn_alignbit(whi, wlo, 16);
+				whi = __builtin_amdgcn_alignbit(j8, whi, 16);
+				++cnt;
+				// word cnt / 4 - 1 of the lane: cnt is a multiple of 4 here, so its address is one shift-add (capacity: see below)
+				if ((cnt & 3u) == 0u) (wp - 64)[(size_t)cnt * 16] = ((uint64_t)whi << 32) | (uint64_t)wlo;
 			};
 			// SELF: the molecule itself lives in the middle row only — the other eight rows skip the index test
 			auto scan_row = [&](int row, auto self_tag) {
 				constexpr bool SELF = decltype(self_tag)::value;
 				const int r0 = rowbase + (row / 3) * (RY * RX) + (row % 3) * RX;
 				const uint32_t jb = cstart[r0], je = cstart[r0 + 3];
-				uint32_t j0 = jb;
-				// full trips: four candidates, two per packed instruction, no range test
-				for (; j0 + 4u <= je; j0 += 4u) {
-					const uint32_t before = cnt;
-					const f32x2 xa = *reinterpret_cast<const f32x2_a4*>(fx + j0), xb = *reinterpret_cast<const f32x2_a4*>(fx + j0 + 2);
-					const f32x2 ya = *reinterpret_cast<const f32x2_a4*>(fy + j0), yb = *reinterpret_cast<const f32x2_a4*>(fy + j0 + 2);
-					const f32x2 za = *reinterpret_cast<const f32x2_a4*>(fz + j0), zb = *reinterpret_cast<const f32x2_a4*>(fz + j0 + 2);
-					const f32x2 dxa = xi - xa, dya = yi - ya, dza = zi - za, dxb = xi - xb, dyb = yi - yb, dzb = zi - zb;
-					const f32x2 ra = __builtin_elementwise_fma(dza, dza, __builtin_elementwise_fma(dya, dya, dxa * dxa));
-					const f32x2 rb = __builtin_elementwise_fma(dzb, dzb, __builtin_elementwise_fma(dyb, dyb, dxb * dxb));
-					put(j0, (ra.x < thr) & (!SELF || j0 != ii));
-					put(j0 + 1u, (ra.y < thr) & (!SELF || j0 + 1u != ii));
-					put(j0 + 2u, (rb.x < thr) & (!SELF || j0 + 2u != ii));
-					put(j0 + 3u, (rb.y < thr) & (!SELF || j0 + 3u != ii));
-					flush(before);
-				}
-				// tail (up to 3 candidates): the entries past the row end are the next cells of the region in linear order,
-				// which at partial bricks may be true neighbours listed again by their own row — hence no overrun here
-				if (j0 < je) {
-					const uint32_t before = cnt;
-					for (uint32_t j = j0; j < je; ++j) {
-						const float dx = xi.x - fx[j], dy = yi.x - fy[j], dz = zi.x - fz[j];
-						const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-						put(j, (r2 < thr) & (!SELF || j != ii));
+				for (uint32_t jblk = jb; jblk < je; jblk += 32u) {
+					const uint32_t nblk = min(32u, je - jblk), ngrp = (nblk + 3u) >> 2;
+					uint32_t m = 0;
+					// m = 2 m + (r^2 < thr): the threshold is folded into the distance (r^2 - thr, first FMA), its sign bit enters the
+					// mask with one v_alignbit
+					auto bit = [&m](float t) { m = __builtin_amdgcn_alignbit(m, __float_as_uint(t), 31); };
+					// groups of four candidates, two per packed instruction.  The last group of a row may run past the row end: those
+					// entries are the next cells of the region in linear order (or the far-away padding behind the last molecule);
+					// their bits are dropped below
+					uint32_t ca = (uint32_t)(uintptr_t)fpos + 12u * jblk;  // LDS byte address of the group's first candidate
+					for (uint32_t g = 0; g < ngrp; ++g, ca += 48u) {
+						// (x0 x1) (y0 y1) (z0 z1) (x2 x3) ... straight into register pairs: ds_read2_b32 takes two independent dword
+						// offsets.  Written as asm: from C++ the compiler pairs ADJACENT dwords and re-sorts with eight v_mov
+						f32x2 xa, ya, za, xb, yb, zb;
+						asm volatile(
+							"ds_read2_b32 %0, %6 offset1:3\n\t"
+							"ds_read2_b32 %1, %6 offset0:1 offset1:4\n\t"
+							"ds_read2_b32 %2, %6 offset0:2 offset1:5\n\t"
+							"ds_read2_b32 %3, %6 offset0:6 offset1:9\n\t"
+							"ds_read2_b32 %4, %6 offset0:7 offset1:10\n\t"
+							"ds_read2_b32 %5, %6 offset0:8 offset1:11\n\t"
+							"s_waitcnt lgkmcnt(0)"
+							: "=&v"(xa), "=&v"(ya), "=&v"(za), "=&v"(xb), "=&v"(yb), "=&v"(zb)
+							: "v"(ca)
+							: "memory");
+						const f32x2 dxa = xi - xa, dya = yi - ya, dza = zi - za, dxb = xi - xb, dyb = yi - yb, dzb = zi - zb;
+						const f32x2 ra = __builtin_elementwise_fma(
+							dza, dza, __builtin_elementwise_fma(dya, dya, __builtin_elementwise_fma(dxa, dxa, nthr)));
+						const f32x2 rb = __builtin_elementwise_fma(
+							dzb, dzb, __builtin_elementwise_fma(dyb, dyb, __builtin_elementwise_fma(dxb, dxb, nthr)));
+						bit(ra.x);
+						bit(ra.y);
+						bit(rb.x);
+						bit(rb.y);
 					}
-					flush(before);
+					// candidate k of the block -> bit 31 - k; bits of candidates past the row end cleared
+					m = (m << (32u - 4u * ngrp)) & (0xffffffffu << (32u - nblk));
+					if (SELF) {
+						const uint32_t d = ii - jblk;
+						if (d < nblk) m &= ~(0x80000000u >> d);
+					}
+					// list capacity, tested once per block instead of once per hit: a lane that would exceed it only counts (its tile
+					// is then marked as overflowed below and evaluated directly by the force pass)
+					const uint32_t hits = (uint32_t)__builtin_popcount(m);
+					if (cnt + hits > (uint32_t)(VMAXW * 4)) {
+						cnt += hits;
+						m = 0;
+					}
+					while (m) {
+						const uint32_t b = (uint32_t)__builtin_clz(m);
+						m &= ~(0x80000000u >> b);
+						put_hit((jblk + b) * 8u);
+					}
 				}
 			};
 			for (int row = 0; row < 4; ++row) scan_row(row, std::false_type());
 			scan_row(4, std::true_type());
 			for (int row = 5; row < 9; ++row) scan_row(row, std::false_type());
-			// the incomplete last word, padded with the dummy entry
+			// the incomplete last word: its entries sit in the top of the register pair; padded with the dummy entry
 			const uint32_t w = cnt >> 2, rem = cnt & 3u;
 			if (rem && w < (uint32_t)VMAXW) {
-				const char* const s0 = winb + ((w & 1u) * (4u * ROWB) + wb);
-				uint64_t word = dummy;
-				for (uint32_t u = 0; u < rem; ++u) {
-					const uint64_t e = *reinterpret_cast<const uint16_t*>(s0 + u * ROWB);
-					word = (word & ~(0xffffull << (16 * u))) | (e << (16 * u));
-				}
-				wp[(size_t)w * 64] = word;
+				const uint64_t part = (((uint64_t)whi << 32) | (uint64_t)wlo) >> (16u * (4u - rem));
+				wp[(size_t)w * 64] = part | (dummy << (16u * rem));
 			}
 		}
 		// words in use by this tile = wave maximum (at least the four rows the force pass loads unconditionally); shorter
@@ -825,9 +841,9 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet_sp(ForceParams P, in
 			for (int c = tid >> 4; c < VNRC; c += NT / 16) {
 				const uint32_t s0 = rec[c], n = rec[c + 1] - s0, g0 = rec[VREC_GBEG + c];
 				for (uint32_t k = 32u + sub; k < n; k += 16u) {
-					fx[s0 + k] = (float)(P.x[g0 + k] - ox);
-					fy[s0 + k] = (float)(P.y[g0 + k] - oy);
-					fz[s0 + k] = (float)(P.z[g0 + k] - oz);
+					fpos[3 * (s0 + k)] = (float)(P.x[g0 + k] - ox);
+					fpos[3 * (s0 + k) + 1] = (float)(P.y[g0 + k] - oy);
+					fpos[3 * (s0 + k) + 2] = (float)(P.z[g0 + k] - oz);
 				}
 			}
 		}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Counter passes for ONE kernel of the bench loop (name substring), summed per counter and divided by the number of launches.
+# Counter passes for chosen kernels of the bench loop (comma-separated name substrings), summed per counter and divided by the number of launches.
 #   usage (inside gpurun):  bash tools/pmc_kernel.sh KERNEL_SUBSTRING OUT.json [bench.py args...]
 set -e -o pipefail
 K=$1; OUT=$2; shift; shift
@@ -17,17 +17,19 @@ for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU 
 done
 python3 - "$K" "$OUT" "$D" <<'PY'
 import csv, glob, json, sys
-k, out, d = sys.argv[1:4]
-acc, n = {}, {}
-for f in glob.glob(d + "/*/*/*counter_collection.csv"):
-    for row in csv.DictReader(open(f)):
+ks, out, d = sys.argv[1:4]
+res = {}
+rows = [row for f in glob.glob(d + "/*/*/*counter_collection.csv") for row in csv.DictReader(open(f))]
+for k in ks.split(","):  # several kernels: comma-separated substrings
+    acc, n = {}, {}
+    for row in rows:
         if k not in row["Kernel_Name"]:
             continue
         c = row["Counter_Name"]
         acc[c] = acc.get(c, 0.0) + float(row["Counter_Value"])
         n[c] = n.get(c, 0) + 1
-res = {c: acc[c] / n[c] for c in acc}
-res["_launches_seen"] = max(n.values()) if n else 0
+    res[k] = {c: acc[c] / n[c] for c in acc}
+    res[k]["_launches_seen"] = max(n.values()) if n else 0
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 print(json.dumps(res, sort_keys=True))
 PY

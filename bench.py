@@ -86,7 +86,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(n_per_dim=50, steps=10, budget_s=150):
+def cpu_baseline(n_per_dim=171, steps=10, budget_s=150):
     """Reference OpenMP CPU path on the host cores: same liquid (bcc lattice start from the reference's own
     CubicGridGenerator), bounded sample N = 2*n^3, `steps` steps."""
     cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("LS1_BENCH_CPU_THREADS", "16")))

@@ -91,15 +91,19 @@ struct VAcc {
 
 // listed pair: exact strict cutoff test; a pair outside gets r2 := 1e300 and every LJ term underflows to exactly 0.
 // COUNT: tally the in-range pairs (they carry the potential shift; also used by the list-free fallbacks).
-template <bool COUNT>
+// SIG1: sigma^2 == 1 (reduced LJ units), sig2 * inv is inv bit for bit — one multiplication less per pair.
+template <bool COUNT, bool SIG1 = false>
 __device__ __forceinline__ void v_pair(double xi, double yi, double zi, double xj, double yj, double zj, double rc2, double eps24,
 									   double sig2, VAcc& a) {
 	const double dx = xi - xj, dy = yi - yj, dz = zi - zj;
 	const double r2 = fma(dz, dz, fma(dy, dy, dx * dx));
 	const bool in = r2 < rc2;
-	// out of range: replace only the HIGH dword by that of 1e300 (one v_cndmask instead of two; any low dword will do)
-	const double inv = v_rcp(__hiloint2double(in ? __double2hiint(r2) : 0x7E37E43C, __double2loint(r2)));
-	const double lj2 = sig2 * inv;
+	// out of range: replace only the HIGH dword by that of 1e300 (one v_cndmask instead of two; any low dword will do).  The
+	// clamped value also feeds the virial term (fac is exactly 0 there, 0 * 1e300 = 0): r2 is then dead and the select happens
+	// in place — no register copy
+	const double d = __hiloint2double(in ? __double2hiint(r2) : 0x7E37E43C, __double2loint(r2));
+	const double inv = v_rcp(d);
+	const double lj2 = SIG1 ? inv : sig2 * inv;
 	const double lj6 = lj2 * lj2 * lj2;
 	const double lj12m6 = fma(lj6, lj6, -lj6);              // lj12 - lj6
 	const double fac = inv * fma(lj6, lj6, lj12m6);          // (lj12 + lj12m6) / r2  // (24 eps applied once per molecule: v_pair_scale)
@@ -108,7 +112,7 @@ __device__ __forceinline__ void v_pair(double xi, double yi, double zi, double x
 	a.fz = fma(fac, dz, a.fz);
 	a.slj += lj12m6;
 	if (COUNT) a.nin += in ? 1u : 0u;
-	a.vir = fma(fac, r2, a.vir);
+	a.vir = fma(fac, d, a.vir);
 }
 
 // the factor 24 eps common to every pair of the molecule
@@ -158,7 +162,7 @@ __device__ __forceinline__ ListHead load_list_head(const ForceParams& P, int bri
 }
 
 // Forces of the owned molecules of ONE brick from the stored lists (positions staged in sx / sy / sz, table in T).
-template <bool SHIFT>
+template <bool SHIFT, bool SIG1 = false>
 __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTab& T, const double* sx, const double* sy,
 											 const double* sz, int brick_id, bool staged, const ListHead& head, Totals& tot,
 											 const uint16_t* fast_ii = nullptr, const uint32_t* fast_gi = nullptr, uint32_t ii0 = 0,
@@ -228,10 +232,10 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 							 z2 = *reinterpret_cast<const double*>(sxb + o2 + 2 * CAPS * 8);
 				const double x3 = *reinterpret_cast<const double*>(sxb + o3), y3 = *reinterpret_cast<const double*>(sxb + o3 + CAPS * 8),
 							 z3 = *reinterpret_cast<const double*>(sxb + o3 + 2 * CAPS * 8);
-				v_pair<SHIFT>(xi, yi, zi, x0, y0, z0, rc2, eps24, sig2, acc);
-				v_pair<SHIFT>(xi, yi, zi, x1, y1, z1, rc2, eps24, sig2, acc);
-				v_pair<SHIFT>(xi, yi, zi, x2, y2, z2, rc2, eps24, sig2, acc);
-				v_pair<SHIFT>(xi, yi, zi, x3, y3, z3, rc2, eps24, sig2, acc);
+				v_pair<SHIFT, SIG1>(xi, yi, zi, x0, y0, z0, rc2, eps24, sig2, acc);
+				v_pair<SHIFT, SIG1>(xi, yi, zi, x1, y1, z1, rc2, eps24, sig2, acc);
+				v_pair<SHIFT, SIG1>(xi, yi, zi, x2, y2, z2, rc2, eps24, sig2, acc);
+				v_pair<SHIFT, SIG1>(xi, yi, zi, x3, y3, z3, rc2, eps24, sig2, acc);
 			};
 			for (uint32_t k = 0; k < nw; k += 4) {
 				// rows past the end are clamped to the last row and evaluated as what they are after the clamp: skipped
@@ -680,7 +684,7 @@ __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int n
 }
 
 // ---- REUSE, one brick per workgroup (reference implementation of the pipeline below; LS1_VL_ONE_BRICK_PER_WG) ---------
-template <bool SHIFT>
+template <bool SHIFT, bool SIG1>
 __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet(ForceParams P, int nbx, int nby, int nbz) {
 	constexpr int CAPS = VCAPS;
 	__shared__ double spos[3 * CAPS];
@@ -726,14 +730,14 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet(ForceParams P, int n
 		// regular brick (staged, every tile has its list): cell table and own indices come from the build's record — no cell
 		// loads, no scans, no table search; the only barrier of the workgroup is the one behind the staging
 		const BrickTab T = {cstart, gbeg, bstart};  // (only the two totals are read on this path)
-		brick_forces<SHIFT>(P, T, sx, sy, sz, bs.id, true, head, tot, f_ii, f_gi, ii0, gi0);
+		brick_forces<SHIFT, SIG1>(P, T, sx, sy, sz, bs.id, true, head, tot, f_ii, f_gi, ii0, gi0);
 	} else {
 		const BrickTab T = {cstart, gbeg, bstart};
 		block_tables(P, bs, T, wsum);
 		const bool staged = cstart[VNRC] <= (uint32_t)VCAPJ;
 		if (staged) stage_positions(P, T, sx, sy, sz);
 		__syncthreads();
-		brick_forces<SHIFT>(P, T, sx, sy, sz, bs.id, staged, head, tot);
+		brick_forces<SHIFT, SIG1>(P, T, sx, sy, sz, bs.id, staged, head, tot);
 	}
 	store_partials(P, tot, red);
 }
@@ -994,8 +998,16 @@ bool launch_force_verlet(const ForceParams& p_in, hipStream_t s, uint32_t* nbloc
 	} else if (p.precision == 2) {
 		if (shift) hipLaunchKernelGGL((k_force_lj_verlet_sp<true, false>), dim3((uint32_t)nb), dim3(VNT), 0, s, p, nbx, nby, nbz);
 		else hipLaunchKernelGGL((k_force_lj_verlet_sp<false, false>), dim3((uint32_t)nb), dim3(VNT), 0, s, p, nbx, nby, nbz);
-	} else if (shift) hipLaunchKernelGGL((k_force_lj_verlet<true>), dim3((uint32_t)nb), dim3(VNT), 0, s, p, nbx, nby, nbz);
-	else hipLaunchKernelGGL((k_force_lj_verlet<false>), dim3((uint32_t)nb), dim3(VNT), 0, s, p, nbx, nby, nbz);
+	} else {
+		const bool sig1 = p.sig2 == 1.0;  // reduced units: one multiplication less per pair, same bits
+		auto go = [&](auto sh, auto s1) {
+			hipLaunchKernelGGL((k_force_lj_verlet<decltype(sh)::value, decltype(s1)::value>), dim3((uint32_t)nb), dim3(VNT), 0, s, p, nbx, nby, nbz);
+		};
+		if (shift && sig1) go(std::true_type{}, std::true_type{});
+		else if (shift) go(std::true_type{}, std::false_type{});
+		else if (sig1) go(std::false_type{}, std::true_type{});
+		else go(std::false_type{}, std::false_type{});
+	}
 	return true;
 }
 

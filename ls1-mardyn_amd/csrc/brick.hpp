@@ -107,6 +107,6 @@ __device__ __forceinline__ void brick_region_table(const ForceParams& P, const B
 
 // number of workgroups of a brick traversal (multiple of 8 for the XCD-aware order); fills p.brick_list / p.n_list for
 // the inner (which = 1) / boundary (2) passes from the host-built lists (kernels_force_lj.hip)
-long plan_bricks(ForceParams& p, BrickLists* bl, int BX, int BY, int BZ, int nbx, int nby, int nbz);
+long plan_bricks(ForceParams& p, BrickLists* bl, int BX, int BY, int BZ, int nbx, int nby, int nbz, bool blocked_order = false);
 
 }  // namespace ls1

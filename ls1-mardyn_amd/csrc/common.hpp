@@ -99,8 +99,8 @@ struct ForceParams {
 // inner / boundary brick lists of the LJ brick kernels for the current grid and brick shape (kernels_force_lj.hip)
 struct BrickLists {
 	int shape[3] = {0, 0, 0}, dims[3] = {0, 0, 0}, hw = 0;
-	uint32_t* d[2] = {nullptr, nullptr};
-	uint32_t n[2] = {0, 0};
+	uint32_t* d[3] = {nullptr, nullptr, nullptr};  // inner bricks, boundary bricks, all bricks (each in blocked order)
+	uint32_t n[3] = {0, 0, 0};
 };
 
 struct Timer {

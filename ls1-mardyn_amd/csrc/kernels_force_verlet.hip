@@ -979,7 +979,13 @@ bool launch_force_verlet(const ForceParams& p_in, hipStream_t s, uint32_t* nbloc
 	const int nbx = (g.box[0] + VBX - 1) / VBX, nby = (g.box[1] + VBY - 1) / VBY, nbz = (g.box[2] + VBZ - 1) / VBZ;
 	if ((long)nbx * nby * nbz <= 0 || (long)nbx * nby * nbz > 0x7ffffff0L) return false;
 	if (p.vl_mode == 1) p.which = 0;  // the lists are always built for all bricks
-	const long nb = plan_bricks(p, bl, VBX, VBY, VBZ, nbx, nby, nbz);  // multiple of 8
+	// blocked launch order of the bricks (kernels_force_lj.hip, brick_lists_for): + 1 % on the 10^8 box; LS1_BRICK_BLOCKED=0
+	// restores the plain x-y-z order
+	static const bool blocked = [] {
+		const char* e = getenv("LS1_BRICK_BLOCKED");
+		return e ? atoi(e) != 0 : true;
+	}();
+	const long nb = plan_bricks(p, bl, VBX, VBY, VBZ, nbx, nby, nbz, blocked);  // multiple of 8
 	if (nb == 0) {
 		*nblocks = 0;
 		return true;

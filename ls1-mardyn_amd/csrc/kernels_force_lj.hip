@@ -705,7 +705,11 @@ long plan_bricks(ForceParams& p, BrickLists* bl, int BX, int BY, int BZ, int nbx
 	p.brick_list = nullptr;
 	p.n_list = 0;
 	p.inner_box = 0;
-	if (p.which == 1) {
+	if (p.which == 1 && blocked_order && brick_lists_for(bl, p.g, BX, BY, BZ, nbx, nby, nbz)) {
+		p.brick_list = bl->d[0];  // the inner bricks in the blocked launch order
+		p.n_list = bl->n[0];
+		n = p.n_list;
+	} else if (p.which == 1) {
 		// "inner" is separable per dimension: bricks [lo, lo + cnt) whose cells lie in [2hw, dims - 2hw)
 		const int B[3] = {BX, BY, BZ}, nbd[3] = {nbx, nby, nbz};
 		const int hw = p.g.hw;

@@ -204,6 +204,8 @@ def main():
                     help="diagnostic (with --decomp): route the local periodic images through the RCCL transport "
                          "(send/recv to the own rank): the full multi-GPU exchange path on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--local-rebuild", type=int, default=-1, choices=[-1, 0, 1],
+                    help="diagnostic: 0 = rebuild the lists by the global displacement bound instead of the brick-neighbourhood one")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="skip the two short rocprofv3 --pmc child passes that measure roofline.traffic live (the figure "
                          "of the committed profiles/ summary is reported instead)")
@@ -290,6 +292,8 @@ def main():
         (sim.engine if sim is not None else eng).set_option("overlap_halo", args.overlap)
     if args.nvt:
         (sim.engine if sim is not None else eng).set_thermostat(True, TEMP)
+    if args.local_rebuild >= 0:
+        (sim.engine if sim is not None else eng).set_option("local_rebuild", args.local_rebuild)
     if args.precision != "dp":
         (sim.engine if sim is not None else eng).set_option("precision", {"spdp": 1, "spsp": 2}[args.precision])
 

@@ -105,6 +105,7 @@ static void free_mol(ls1hip_ctx* c) {
 	c->vl_ready = false;
 	dfree(c->alt_x); dfree(c->alt_y); dfree(c->alt_z);
 	dfree(c->d_vl_words); dfree(c->d_vl_nw); dfree(c->d_vl_rec); dfree(c->d_vl_ii); dfree(c->d_vl_gi);
+	dfree(c->d_vl_top2); dfree(c->d_vl_acc);
 	dfree(c->seam_a_buf);
 	c->seam_a_cap = 0;
 	c->vl_words_cap = c->vl_tiles_cap = 0;
@@ -220,6 +221,8 @@ extern "C" int ls1hip_set_option(ls1hip_ctx* c, const char* name, long v) {
 	} else if (n == "precision") {
 		REQUIRE(c, v >= 0 && v <= 2, "precision must be 0 (FP64), 1 (SPDP) or 2 (SPSP)");
 		c->opt_precision = v;
+	} else if (n == "local_rebuild") {
+		c->opt_local_rebuild = v ? 1 : 0;
 	} else if (n == "lj_split") {
 		REQUIRE(c, v == 0 || v == 1 || v == 2 || v == 4 || v == 5 || v == 6, "lj_split must be 0 (auto), 1, 2 (list kernel lanes per molecule), 4, 5 or 6 (MFMA pre-filter variants)");
 		c->opt_lj_split = v;
@@ -241,6 +244,7 @@ extern "C" int ls1hip_get_option(const ls1hip_ctx* c, const char* name, long* v)
 	else if (n == "fuse_integration") *v = c->opt_fuse;
 	else if (n == "overlap_halo") *v = c->opt_overlap_halo;
 	else if (n == "precision") *v = c->opt_precision;
+	else if (n == "local_rebuild") *v = c->opt_local_rebuild;
 	else if (n == "verlet_irregular_bricks") *v = c->h_cnt ? (long)c->h_cnt->vl_irregular : 0;  // as of the last build in a single-precision mode
 	else if (n == "precision_in_use") *v = (c->opt_precision && c->vl_ready && c->vl_all_regular) ? c->opt_precision : 0;
 	else if (n == "can_fuse_integration") *v = can_fuse(c) ? 1 : 0;
@@ -951,9 +955,13 @@ static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
 	int family = LS1HIP_FK_LDS_LIST;
 	const double ncell = (double)c->g.box[0] * c->g.box[1] * c->g.box[2];
 	const double mean_per_cell = ncell > 0 ? (double)c->n_real / ncell : 0.;
+	// local rebuild criterion (kernels_force_verlet.hip, k_bound_local): complete fused FP64 traversals of a single periodic domain
+	const bool local_crit = fp.vl && fuse && which == 0 && !c->has_remote && c->opt_local_rebuild && P.precision == 0 && c->d_vl_top2;
+	if (local_crit) P.vl_top2 = c->d_vl_top2;
 	if (fp.vl) {
 		done = launch_force_verlet(P, c->stream, &nblocks, c->partials_cap, &c->brick_lists);
 		if (!done) FAIL(c, LS1HIP_EINVAL, "neighbour-list force pass could not be launched");
+		if (local_crit) launch_bound_local(c->g, c->d_vl_top2, c->d_vl_acc, c->d_cnt, fp.dt, 0.5 * c->vl_skin, c->stream);
 	} else if (c->one_clj && c->opt_force_kernel != LS1HIP_FK_GENERIC && !c->opt_vi && !c->opt_count_pairs) {
 		done = launch_force_lj(P, c->stream, &nblocks, c->d_partials, c->partials_cap, (int)c->opt_lj_split, mean_per_cell,
 							   &c->brick_lists);
@@ -994,6 +1002,7 @@ static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
 		rm.lists_rebuilt = fp.lists_rebuilt;
 		rm.dt = fp.dt;
 		rm.limit = 0.5 * c->vl_skin;
+		rm.local_criterion = local_crit;
 		rm.seq = ++c->vl_seq;
 		rm.flag = c->d_flag;
 	}
@@ -1365,11 +1374,14 @@ static int ensure_verlet_buffers(ls1hip_ctx* c) {
 		dfree(c->d_vl_rec);
 		dfree(c->d_vl_ii);
 		dfree(c->d_vl_gi);
+		dfree(c->d_vl_top2);
+		dfree(c->d_vl_acc);
 		c->vl_words_cap = c->vl_tiles_cap = 0;
 		int rc;
 		if ((rc = dalloc(c, &c->d_vl_words, words)) || (rc = dalloc(c, &c->d_vl_nw, tiles)) ||
 			(rc = dalloc(c, &c->d_vl_rec, (size_t)nbricks * verlet_record_words())) || (rc = dalloc(c, &c->d_vl_ii, tiles * 64)) ||
-			(rc = dalloc(c, &c->d_vl_gi, tiles * 64)))
+			(rc = dalloc(c, &c->d_vl_gi, tiles * 64)) || (rc = dalloc(c, &c->d_vl_top2, (size_t)nbricks * 2)) ||
+			(rc = dalloc(c, &c->d_vl_acc, (size_t)nbricks)))
 			return rc;
 		c->vl_words_cap = words;
 		c->vl_tiles_cap = tiles;
@@ -1396,6 +1408,10 @@ static int verlet_build(ls1hip_ctx* c) {
 	P.vl_mode = 1;
 	uint32_t nb = 0;
 	HIPCHK(c, hipMemsetAsync(&c->d_cnt->vl_irregular, 0, sizeof(uint32_t), c->stream));
+	// local rebuild criterion: the per-brick bounds, the share of unfused drifts and the verdict start at zero with the lists
+	HIPCHK(c, hipMemsetAsync(c->d_vl_acc, 0, (size_t)verlet_brick_count(c->g) * sizeof(double), c->stream));
+	HIPCHK(c, hipMemsetAsync(&c->d_cnt->vl_base, 0, sizeof(double), c->stream));
+	HIPCHK(c, hipMemsetAsync(&c->d_cnt->vl_local_excess, 0, sizeof(uint32_t), c->stream));
 	if (!launch_force_verlet(P, c->stream, &nb, c->partials_cap, &c->brick_lists))
 		FAIL(c, LS1HIP_EINVAL, "neighbour lists could not be built for this grid");
 	HIPCHK(c, hipGetLastError());

@@ -52,9 +52,11 @@ struct DevCounters {
 	uint32_t err_ingest;   // uploaded molecules outside the bounding box of this rank / with a wrong component id
 	uint32_t err_ingest_first;  // index (in upload order) of one offending molecule
 	uint32_t vl_irregular;      // list build: bricks without a complete set of stored lists (unstaged, overflow)
+	uint32_t vl_local_excess;   // local rebuild criterion: some brick neighbourhood's pair-displacement bound exceeds skin / 2
 	unsigned long long dist_checks, pairs_in_range;
 	double vmax2;          // list-reuse mode: max |v|^2 of the drift velocities of the current step
 	double vl_bound;       // upper bound of the displacement of any molecule since the neighbour lists were built
+	double vl_base;        // local criterion: the part of that bound added by UNFUSED drifts (they only know the global v_max)
 	double macro[4];       // u6, uX, rf, virial of the current traversal
 	double kin[2];         // sum m v^2, sum I w^2
 	double beta[2];        // thermostat factors derived from kin (beta_trans, beta_rot)
@@ -94,6 +96,7 @@ struct ForceParams {
 	uint32_t* vl_rec;    // [brick][verlet_record_words()]: region cell table + flags, written by the build
 	uint16_t* vl_ii;     // [brick][tiles * 64]: LDS slot of every owned molecule
 	uint32_t* vl_gi;     // [brick][tiles * 64]: global index of every owned molecule
+	double* vl_top2;     // [brick][2] or nullptr: the two largest |v_drift|^2 of the brick's owned molecules (local rebuild criterion)
 };
 
 // inner / boundary brick lists of the LJ brick kernels for the current grid and brick shape (kernels_force_lj.hip)
@@ -193,6 +196,9 @@ struct ls1hip_ctx {
 	uint32_t* d_vl_rec = nullptr;
 	uint16_t* d_vl_ii = nullptr;
 	uint32_t* d_vl_gi = nullptr;
+	double* d_vl_top2 = nullptr;  // [brick][2] two largest |v_drift|^2 per brick (local rebuild criterion)
+	double* d_vl_acc = nullptr;   // [brick] accumulated pair-displacement bound of the brick's neighbourhood
+	long opt_local_rebuild = 1;   // single periodic domain, fused FP64 list passes: rebuild by the local criterion
 	size_t vl_words_cap = 0, vl_tiles_cap = 0;
 	double *alt_x = nullptr, *alt_y = nullptr, *alt_z = nullptr;  // second position buffer (owned + halo segment)
 	bool vl_valid = false;       // the lists match the current binning and the displacement bound is tracked on the device
@@ -325,7 +331,9 @@ void verlet_geometry(const Grid& g, long* nbricks, size_t* words_per_brick, size
 int verlet_region_capacity();  // molecules of a brick's region the list kernels can stage in LDS
 int verlet_region_cells();
 void verlet_brick_shape(int shape[3]);
-int verlet_record_words();  // cells per brick edge of the list kernels
+int verlet_record_words();
+void launch_bound_local(const Grid& g, const double* top2, double* acc, DevCounters* cnt, double dt, double limit, hipStream_t s);
+long verlet_brick_count(const Grid& g);  // cells per brick edge of the list kernels
 // brick-tiled multi-site kernel (kernels_force_ms.hip); returns false if it cannot handle the configuration
 bool launch_force_ms(const ForceParams& p, bool with_vi, bool has_rot, bool one_component, hipStream_t s, uint32_t* nblocks,
 					 size_t partials_cap, double mean_per_cell, BrickLists* bl);
@@ -343,6 +351,7 @@ struct ReduceMode {
 	// advanced by dt * sqrt(vmax2) (after being reset when the lists were rebuilt in this step) and the rebuild flag
 	// {seq, bound > limit} is published to the host-visible word `flag`.
 	bool vmax_in_slot2 = false, last_pass = false, lists_rebuilt = false;
+	bool local_criterion = false;  // the rebuild flag comes from cnt->vl_local_excess (k_bound_local ran before the reduction)
 	double dt = 0., limit = 0.;
 	uint32_t seq = 0;
 	volatile uint32_t* flag = nullptr;

@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(256) k_force_reduce1(const double* partials, u
 	}
 }
 struct Reduce2Args {
-	int overwrite, kin_in_slot1, vmax_in_slot2, last_pass, lists_rebuilt;
+	int overwrite, kin_in_slot1, vmax_in_slot2, last_pass, lists_rebuilt, local_criterion;
 	double dt, limit;
 	uint32_t seq;
 	volatile uint32_t* flag;
@@ -345,9 +345,18 @@ __global__ void __launch_bounds__(RED_BLOCKS) k_force_reduce2(DevCounters* cnt, 
 				// build time, so they stay complete while 2 * bound <= skin
 				const double b = (m.lists_rebuilt ? 0. : cnt->vl_bound) + m.dt * sqrt(cnt->vmax2);
 				cnt->vl_bound = b;
+				// a fused pass WITHOUT the per-brick bookkeeping counts with the global speed for every brick (as unfused drifts do)
+				if (!m.local_criterion) cnt->vl_base = (m.lists_rebuilt ? 0. : cnt->vl_base) + m.dt * sqrt(cnt->vmax2);
+				// local criterion (k_bound_local, kernels_force_verlet.hip): a brick neighbourhood's pair bound decides; it is never
+				// earlier than the global one
+				bool rebuild = b > m.limit;
+				if (m.local_criterion) {
+					rebuild = rebuild && cnt->vl_local_excess != 0u;
+					cnt->vl_local_excess = 0u;
+				}
 				if (m.flag) {
 					__threadfence_system();
-					*m.flag = (m.seq << 1) | (b > m.limit ? 1u : 0u);
+					*m.flag = (m.seq << 1) | (rebuild ? 1u : 0u);
 					__threadfence_system();
 				}
 			}
@@ -374,7 +383,7 @@ void launch_force_reduce(DevCounters* cnt, const double* partials, uint32_t nblo
 	}
 	Reduce2Args a;
 	a.overwrite = m.overwrite; a.kin_in_slot1 = m.kin_in_slot1; a.vmax_in_slot2 = m.vmax_in_slot2; a.last_pass = m.last_pass;
-	a.lists_rebuilt = m.lists_rebuilt; a.dt = m.dt; a.limit = m.limit; a.seq = m.seq; a.flag = m.flag; a.log = m.log;
+	a.lists_rebuilt = m.lists_rebuilt; a.local_criterion = m.local_criterion; a.dt = m.dt; a.limit = m.limit; a.seq = m.seq; a.flag = m.flag; a.log = m.log;
 	a.target_T = m.target_T;
 	hipLaunchKernelGGL(k_force_reduce1, dim3(RED_BLOCKS), dim3(256), 0, s, partials, nblocks, stage, m.vmax_in_slot2 ? 1 : 0);
 	hipLaunchKernelGGL(k_force_reduce2, dim3(1), dim3(RED_BLOCKS), 0, s, cnt, stage, a);

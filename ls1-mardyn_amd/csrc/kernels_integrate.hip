@@ -316,6 +316,7 @@ __global__ void __launch_bounds__(RTPB) k_bound_update(DevCounters* cnt, const d
 		for (int i = 0; i < RTPB / 64; ++i) m = fmax(m, red[i]);
 		const double b = (fresh ? 0. : cnt->vl_bound) + dt * sqrt(m);
 		cnt->vl_bound = b;
+		cnt->vl_base = (fresh ? 0. : cnt->vl_base) + dt * sqrt(m);  // local criterion: unfused drifts count for every brick
 		if (flag) {
 			__threadfence_system();
 			*flag = (seq << 1) | (b > limit ? 1u : 0u);

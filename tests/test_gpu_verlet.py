@@ -305,3 +305,42 @@ def test_single_precision_list_pass_against_fp64(precision, tol_f, tol_traj):
         res[prec] = _state(e)[3]
         e.close()
     assert np.array_equal(res[0], res[precision])
+
+
+def test_local_rebuild_criterion_with_fast_outliers():
+    """Rebuild decision by brick neighbourhoods (k_bound_local: sum of dt * (s1 + s2) / 2 over the two largest speeds of the 27
+    bricks around a brick) instead of the global sum of dt * v_max.  One molecule at four times the thermal maximum
+    makes the two criteria differ by almost a factor of two — and any listed pair the local one released too early would
+    show as a force error of order 1e-2: the trajectory must still be that of the per-step kernels, with fewer builds than the
+    global criterion needs.  A second run mixes fused and unfused drifts (runs of 7 steps: the first step of every run
+    integrates separately) — the unfused ones must count for every brick."""
+    n, dt, steps = 40, 0.002, 63
+    L, ids, r, v = synth.bcc_box(n, temp=0.95)
+    rng = np.random.default_rng(3)
+    fast = rng.choice(len(ids), 1, replace=False)  # (two of them would share a 27-brick neighbourhood of this small box)
+    d = rng.normal(size=(1, 3))
+    v = v.copy()
+    v[fast] = 16.0 * d / np.linalg.norm(d, axis=1)[:, None]
+    res, builds = {}, {}
+    for mode, skin, opts, chunk in (("step", None, {}, steps), ("local", 0.3, {}, steps), ("global", 0.3, {"local_rebuild": 0}, steps),
+                                    ("mixed", 0.3, {}, 7)):
+        e = _engine(_lj(), 2.5, [L] * 3, ids, r, v, skin=skin, **opts)
+        for _ in range(steps // chunk):
+            out = e.run(dt, chunk)
+        res[mode] = _state(e) + (out,)
+        if skin:
+            builds[mode] = e.get_option("verlet_builds")
+        e.close()
+    assert builds["local"] < builds["global"], builds   # the criterion is active ...
+    assert builds["local"] >= builds["global"] // 2, builds   # ... and still bounded by the pair argument (s2 > 0)
+    a = res["step"]
+    for mode in ("local", "global", "mixed"):
+        b = res[mode]
+        assert np.array_equal(a[0], b[0])
+        dr = a[1] - b[1]
+        dr -= L * np.round(dr / L)
+        assert np.max(np.abs(dr)) < 1e-10 * L, mode
+        assert rel_max(b[2], a[2]) < 1e-10, mode
+        assert rel_max(b[3], a[3]) < 1e-9, mode
+        for k in ("upot", "virial", "summv2"):
+            assert abs(a[4][k] - b[4][k]) <= 1e-10 * abs(a[4][k]), (mode, k)

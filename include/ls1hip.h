@@ -76,7 +76,7 @@ const char* ls1hip_version(void);
  *   MARDYN_SPDP / MARDYN_SPSP build modes, vectorization/RealVec.h, RealAccumVecSPDP.h: pair arithmetic in FP32, sums in
  *   FP64 / FP32; molecule state, integration and reductions stay FP64; used while every brick of the last list build is
  *   regular, read-only "precision_in_use" tells),
- * "local_rebuild" (neighbour-list loop of a single periodic domain, fused FP64 passes: 1 (default) = the lists are rebuilt when
+ * "local_rebuild" (neighbour-list loop of a single periodic domain, fused passes: 1 (default) = the lists are rebuilt when
  * the pair-displacement bound of some brick neighbourhood exceeds skin / 2 — sum over the steps of dt * (s1 + s2) / 2, s1 >= s2
  * the two largest speeds among the molecules of the 27 bricks around a brick; 0 = global bound, sum of dt * v_max; both are
  * rigorous, the local one is never earlier),

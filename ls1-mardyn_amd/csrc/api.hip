@@ -955,8 +955,8 @@ static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
 	int family = LS1HIP_FK_LDS_LIST;
 	const double ncell = (double)c->g.box[0] * c->g.box[1] * c->g.box[2];
 	const double mean_per_cell = ncell > 0 ? (double)c->n_real / ncell : 0.;
-	// local rebuild criterion (kernels_force_verlet.hip, k_bound_local): complete fused FP64 traversals of a single periodic domain
-	const bool local_crit = fp.vl && fuse && which == 0 && !c->has_remote && c->opt_local_rebuild && P.precision == 0 && c->d_vl_top2;
+	// local rebuild criterion (kernels_force_verlet.hip, k_bound_local): complete fused traversals of a single periodic domain
+	const bool local_crit = fp.vl && fuse && which == 0 && !c->has_remote && c->opt_local_rebuild && c->d_vl_top2;
 	if (local_crit) P.vl_top2 = c->d_vl_top2;
 	if (fp.vl) {
 		done = launch_force_verlet(P, c->stream, &nblocks, c->partials_cap, &c->brick_lists);

@@ -984,7 +984,11 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet_sp(ForceParams P, in
 				P.vx[gi] = vx;
 				P.vy[gi] = vy;
 				P.vz[gi] = vz;
-				tot.vmax2 = fmax(tot.vmax2, vx * vx + vy * vy + vz * vz);
+				{
+					const double v2 = vx * vx + vy * vy + vz * vz;
+					tot.vmax2b = fmax(tot.vmax2b, fmin(tot.vmax2, v2));
+					tot.vmax2 = fmax(tot.vmax2, v2);
+				}
 				P.Fx[gi] = x0 + P.dt * vx;
 				P.Fy[gi] = y0 + P.dt * vy;
 				P.Fz[gi] = z0 + P.dt * vz;
@@ -993,7 +997,7 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet_sp(ForceParams P, in
 			tot.vir += eps24 * dvir;
 		}
 	}
-	store_partials(P, tot, red);
+	store_partials(P, tot, red, bs.id);
 }
 
 // ---- LOCAL REBUILD CRITERION ------------------------------------------------------------------------------------------------

@@ -52,6 +52,7 @@ enum {
 #define LS1HIP_FK_LDS_LIST 2  /* brick-tiled, LDS-staged, per-lane neighbour lists (1CLJ)    */
 #define LS1HIP_FK_MS_BRICK 3  /* multi-site, LDS-staged molecule pairs; bitwise == GENERIC (AUTO's choice for multi-site sets) */
 #define LS1HIP_FK_MS_SITES 4  /* multi-site, LDS tables + cached own sites + FMA bodies; 1e-12 of GENERIC; on request only   */
+#define LS1HIP_FK_NEIGHBOUR_LIST 5 /* reported by "last_force_kernel" only: forces from the stored neighbour lists (ls1hip_set_verlet) */
 
 /* ---- lifetime ------------------------------------------------------------------------------------------------- */
 
@@ -71,7 +72,7 @@ const char* ls1hip_version(void);
  * "count_pairs" (0|1 tally molecule pairs / site interactions inside the cutoff for ls1hip_pair_stats — the
  * counters of adapter/FlopCounter.cpp:20-76; forces then use the generic kernel),
  * "last_force_kernel" (read only: kernel family of the last force launch — LS1HIP_FK_*: 1 generic, 2 single-centre LJ brick
- *   kernels, 3 multi-site brick kernel, 4 multi-site site kernel; lets callers / tests see a fallback to the generic kernel),
+ *   kernels, 3 multi-site brick kernel, 4 multi-site site kernel, 5 neighbour-list force pass; lets callers / tests see a fallback to the generic kernel),
  * "precision" (list force pass of the single-centre LJ path: 0 = FP64 (default), 1 = SPDP, 2 = SPSP — the reference's
  *   MARDYN_SPDP / MARDYN_SPSP build modes, vectorization/RealVec.h, RealAccumVecSPDP.h: pair arithmetic in FP32, sums in
  *   FP64 / FP32; molecule state, integration and reductions stay FP64; used while every brick of the last list build is

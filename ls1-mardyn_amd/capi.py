@@ -80,7 +80,7 @@ SYMBOLS = {
 LEAVING_DOUBLES = 15
 HALO_DOUBLES = 9
 REFRESH_DOUBLES = 3
-FK_AUTO, FK_GENERIC, FK_LDS_LIST, FK_MS_BRICK, FK_MS_SITES = 0, 1, 2, 3, 4
+FK_AUTO, FK_GENERIC, FK_LDS_LIST, FK_MS_BRICK, FK_MS_SITES, FK_NEIGHBOUR_LIST = 0, 1, 2, 3, 4, 5
 REC_ICRVQD, REC_ICRV, REC_IRV = 0, 1, 2
 REC_BYTES = {REC_ICRVQD: 116, REC_ICRV: 60, REC_IRV: 56}
 

@@ -245,7 +245,18 @@ extern "C" int ls1hip_get_option(const ls1hip_ctx* c, const char* name, long* v)
 	else if (n == "overlap_halo") *v = c->opt_overlap_halo;
 	else if (n == "precision") *v = c->opt_precision;
 	else if (n == "local_rebuild") *v = c->opt_local_rebuild;
-	else if (n == "verlet_irregular_bricks") *v = c->h_cnt ? (long)c->h_cnt->vl_irregular : 0;  // as of the last build in a single-precision mode
+	else if (n == "verlet_irregular_bricks") {
+		// bricks of the last list build that do NOT run the production path of the list force pass (region beyond the LDS staging
+		// area, list overflow, more owned molecules than the tiles cover): read back from the device on request, any precision
+		*v = 0;
+		if (c->vl_ready && c->d_cnt) {
+			uint32_t k = 0;
+			if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
+				hipMemcpy(&k, &c->d_cnt->vl_irregular, sizeof(k), hipMemcpyDeviceToHost) != hipSuccess)
+				return LS1HIP_EHIP;
+			*v = (long)k;
+		}
+	}
 	else if (n == "precision_in_use") *v = (c->opt_precision && c->vl_ready && c->vl_all_regular) ? c->opt_precision : 0;
 	else if (n == "can_fuse_integration") *v = can_fuse(c) ? 1 : 0;
 	else if (n == "last_force_kernel") *v = c->last_force_kernel;
@@ -961,6 +972,7 @@ static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
 	if (fp.vl) {
 		done = launch_force_verlet(P, c->stream, &nblocks, c->partials_cap, &c->brick_lists);
 		if (!done) FAIL(c, LS1HIP_EINVAL, "neighbour-list force pass could not be launched");
+		family = LS1HIP_FK_NEIGHBOUR_LIST;
 		if (local_crit) launch_bound_local(c->g, c->d_vl_top2, c->d_vl_acc, c->d_cnt, fp.dt, 0.5 * c->vl_skin, c->stream);
 	} else if (c->one_clj && c->opt_force_kernel != LS1HIP_FK_GENERIC && !c->opt_vi && !c->opt_count_pairs) {
 		done = launch_force_lj(P, c->stream, &nblocks, c->d_partials, c->partials_cap, (int)c->opt_lj_split, mean_per_cell,

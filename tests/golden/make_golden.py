@@ -54,9 +54,20 @@ CASES = [
     ("bcc1clj_3456", "synthetic:bcc1clj:12", 2.5, 1, 0, 0.0, 0),
     ("bcc1clj_3456_steps10", "synthetic:bcc1clj:12", 2.5, 1, 10, 0.005, 0),
     ("bcc1clj_16000", "synthetic:bcc1clj:20", 2.5, 1, 0, 0.0, 0),
+    # round 3: a trajectory on the box whose brick regions FIT the LDS staging area of the neighbour-list kernels (16 molecules
+    # per cell at skin 0.2), i.e. the production configuration of the list loop; 20 steps span >= 3 list lifetimes
+    ("bcc1clj_16000_steps20", "synthetic:bcc1clj:20", 2.5, 1, 20, 0.005, 0),
     # global velocity-scaling thermostat active (legacy flag value 2 = --nvt): SURVEY 8f-1
     ("bcc1clj_3456_nvt10", "synthetic:bcc1clj:12", 2.5, 1, 10, 0.005, 2),
     ("ethan_nvt5", "Ethan_equilibrated.inp", 32.1254, 1, 5, 0.5, 2),
+    # round 3: the reference's single-precision build modes (legacy flag value 3 = refdump_spdp, built -DMARDYN_SPDP: FP32 pair
+    # arithmetic, FP64 sums; 4 = refdump_spsp, -DMARDYN_SPSP: FP32 sums too; cmake/modules/options.cmake:13-15) on a box whose
+    # brick regions fit the staging area of the list kernels (8 cells per dimension at skin 0.2, 16 molecules per cell)
+    ("bcc1clj_8192_spdp", "synthetic:bcc1clj:16", 2.5, 1, 0, 0.0, 3),
+    ("bcc1clj_8192_spsp", "synthetic:bcc1clj:16", 2.5, 1, 0, 0.0, 4),
+    ("bcc1clj_8192_spdp_steps10", "synthetic:bcc1clj:16", 2.5, 1, 10, 0.005, 3),
+    ("bcc1clj_8192_spsp_steps10", "synthetic:bcc1clj:16", 2.5, 1, 10, 0.005, 4),
+    ("bcc1clj_8192", "synthetic:bcc1clj:16", 2.5, 1, 0, 0.0, 0),
 ]
 
 
@@ -105,7 +116,13 @@ def main():
     os.makedirs(INPUTS, exist_ok=True)
     if not os.path.exists(REFDUMP):
         subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle", "ref_build")])
+    for tgt in ("spdp", "spsp"):
+        if not os.path.exists(REFDUMP + "_" + tgt):
+            subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle", "ref_build"), tgt])
+    only = set(sys.argv[1:])  # optional: regenerate the named cases only
     for name, inp, rc, periodic, steps, dt, legacy in CASES:
+        if only and name not in only:
+            continue
         if inp.startswith("synthetic:"):
             fname = inp.replace(":", "_") + ".inp"
             local = os.path.join(INPUTS, fname)
@@ -124,7 +141,7 @@ def main():
                 shutil.copyfileobj(fi, fo)
             src = tmp
         out = os.path.join(HERE, name + ".bin")
-        cmd = [REFDUMP, src, repr(rc), str(periodic), out]
+        cmd = [REFDUMP + {3: "_spdp", 4: "_spsp"}.get(legacy, ""), src, repr(rc), str(periodic), out]
         if legacy == 1:
             cmd.append("--legacy")
         if legacy == 2:

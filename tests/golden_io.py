@@ -13,15 +13,21 @@ REC = np.dtype([("id", "<u8"), ("cid", "<u8"), ("r", "<f8", 3), ("v", "<f8", 3),
                 ("D", "<f8", 3), ("F", "<f8", 3), ("M", "<f8", 3), ("Vi", "<f8", 3)])
 
 
-def manifest():
+def manifest(single_precision=False):
+    """Golden cases of MANIFEST.txt.  Column `legacy`: 0 = VectorizedCellProcessor (FP64 build), 1 = LegacyCellProcessor,
+    2 = with the velocity-scaling thermostat, 3 / 4 = the reference built with -DMARDYN_SPDP / -DMARDYN_SPSP (returned only
+    with single_precision=True: every other test iterates over the FP64 cases and their 1e-10 tolerances)."""
     out = {}
     with open(os.path.join(GOLDEN, "MANIFEST.txt")) as fh:
         for ln in fh:
             if ln.startswith("#") or not ln.strip():
                 continue
             name, inp, rc, periodic, steps, dt, legacy = ln.split()
+            prec = {3: 1, 4: 2}.get(int(legacy), 0)
+            if bool(prec) != bool(single_precision):
+                continue
             out[name] = dict(name=name, input=inp, rc=float(rc), periodic=int(periodic), steps=int(steps),
-                             dt=float(dt), legacy=int(int(legacy) == 1), nvt=int(int(legacy) == 2))
+                             dt=float(dt), legacy=int(int(legacy) == 1), nvt=int(int(legacy) == 2), precision=prec)
     return out
 
 

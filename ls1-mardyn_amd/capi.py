@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libls1hip.so")
+# LS1HIP_LIB: another build of the SAME library (tools/ab_variant.sh: same-box A/B timing of kernel variants); never a fallback
+LIB_PATH = os.environ.get("LS1HIP_LIB") or os.path.join(_HERE, "lib", "libls1hip.so")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)

@@ -50,7 +50,11 @@ constexpr int VNW = VNT / 64;
 constexpr int VRX = VBX + 2, VRY = VBY + 2, VRZ = VBZ + 2;
 constexpr int VNRC = VRX * VRY * VRZ;  // 144 region cells
 constexpr int VNBC = VBX * VBY * VBZ;  // 32 brick cells
+#ifdef LS1_N3_MOCK
+constexpr int VCAPJ = 2560;            // TIMING MOCK of brick-internal Newton 3 (tools/ab_variant.sh): room for the LDS force accumulators
+#else
 constexpr int VCAPJ = 2816;            // staged molecules per brick region (67.8 KB of x, y, z)
+#endif
 constexpr int VCAPS = VCAPJ + 8;       // +8: the dummy slot and the overrun of unrolled row reads
 constexpr int VMAXT = 10;    // tiles per brick with stored lists (640 owned molecules); further tiles: direct evaluation
 constexpr int VMAXW = 24;    // words per lane = 96 list entries
@@ -114,6 +118,36 @@ __device__ __forceinline__ void v_pair(double xi, double yi, double zi, double x
 	if (COUNT) a.nin += in ? 1u : 0u;
 	a.vir = fma(fac, d, a.vir);
 }
+
+#ifdef LS1_N3_MOCK
+// TIMING MOCK (results are wrong by construction): what brick-internal Newton 3 would cost.  A third of a molecule's list entries
+// disappear (pairs inside the brick are listed by one partner only), and half of the remaining ones return their force to the
+// partner's LDS accumulator with three ds_add_f64.
+__shared__ double g_sacc[3 * 512];
+template <bool COUNT, bool SIG1 = false>
+__device__ __forceinline__ void v_pair_n3(double xi, double yi, double zi, double xj, double yj, double zj, double rc2, double eps24,
+										  double sig2, VAcc& a, uint32_t slot) {
+	const double dx = xi - xj, dy = yi - yj, dz = zi - zj;
+	const double r2 = fma(dz, dz, fma(dy, dy, dx * dx));
+	const bool in = r2 < rc2;
+	const double d = __hiloint2double(in ? __double2hiint(r2) : 0x7E37E43C, __double2loint(r2));
+	const double inv = v_rcp(d);
+	const double lj2 = SIG1 ? inv : sig2 * inv;
+	const double lj6 = lj2 * lj2 * lj2;
+	const double lj12m6 = fma(lj6, lj6, -lj6);
+	const double fac = inv * fma(lj6, lj6, lj12m6);
+	const double fx = fac * dx, fy = fac * dy, fz = fac * dz;
+	a.fx += fx;
+	a.fy += fy;
+	a.fz += fz;
+	unsafeAtomicAdd(&g_sacc[slot], -fx);
+	unsafeAtomicAdd(&g_sacc[slot + 512], -fy);
+	unsafeAtomicAdd(&g_sacc[slot + 1024], -fz);
+	a.slj += lj12m6;
+	if (COUNT) a.nin += in ? 1u : 0u;
+	a.vir = fma(fac, d, a.vir);
+}
+#endif
 
 // the factor 24 eps common to every pair of the molecule
 __device__ __forceinline__ void v_pair_scale(VAcc& a, double eps24) {
@@ -215,7 +249,11 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 			// row register is reloaded right after its content is consumed — ONE loop-carried value per row: with a rotating
 			// window (w0 <- w1 <- w2 <- w3) the compiler sank every load to its use and waited vmcnt(0) on it, i.e. a dependent
 			// HBM round trip per four pairs; a load inside a branch has the same effect (seen in the ISA).
+#if defined(LS1_N3_MOCK) || defined(LS1_SHORT_MOCK)
+			const uint32_t last = max(4u, (nw * 2u + 2u) / 3u) - 1u;
+#else
 			const uint32_t last = nw - 1u;  // nw >= 4: rows are dummy-padded by the build
+#endif
 			uint64_t r0 = head.w0, r1 = head.w1;  // first tile: loaded ahead by the caller (rows 0 and 1)
 			if (pass != 0) {
 				r0 = load_row(wp);
@@ -233,11 +271,24 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 							 z2 = *reinterpret_cast<const double*>(sxb + o2 + 2 * CAPS * 8);
 				const double x3 = *reinterpret_cast<const double*>(sxb + o3), y3 = *reinterpret_cast<const double*>(sxb + o3 + CAPS * 8),
 							 z3 = *reinterpret_cast<const double*>(sxb + o3 + 2 * CAPS * 8);
+#ifdef LS1_N3_MOCK
+				v_pair_n3<SHIFT, SIG1>(xi, yi, zi, x0, y0, z0, rc2, eps24, sig2, acc, (o0 >> 3) & 511u);
+				v_pair<SHIFT, SIG1>(xi, yi, zi, x1, y1, z1, rc2, eps24, sig2, acc);
+				v_pair_n3<SHIFT, SIG1>(xi, yi, zi, x2, y2, z2, rc2, eps24, sig2, acc, (o2 >> 3) & 511u);
+				v_pair<SHIFT, SIG1>(xi, yi, zi, x3, y3, z3, rc2, eps24, sig2, acc);
+#else
 				v_pair<SHIFT, SIG1>(xi, yi, zi, x0, y0, z0, rc2, eps24, sig2, acc);
 				v_pair<SHIFT, SIG1>(xi, yi, zi, x1, y1, z1, rc2, eps24, sig2, acc);
 				v_pair<SHIFT, SIG1>(xi, yi, zi, x2, y2, z2, rc2, eps24, sig2, acc);
 				v_pair<SHIFT, SIG1>(xi, yi, zi, x3, y3, z3, rc2, eps24, sig2, acc);
+#endif
 			};
+#ifdef LS1_N3_MOCK
+			nw = max(4u, (nw * 2u + 2u) / 3u);
+#endif
+#ifdef LS1_SHORT_MOCK
+			nw = max(4u, (nw * 2u + 2u) / 3u);  // the shorter lists alone (no accumulator traffic)
+#endif
 			for (uint32_t k = 0; k < nw; k += 4) {
 				// rows past the end are clamped to the last row and evaluated as what they are after the clamp: skipped
 				four_pairs(r0);

@@ -97,7 +97,7 @@ void LinkedCellsHip::clear() {
 }
 
 void LinkedCellsHip::deleteMolecule(ParticleIterator& moleculeIter, const bool& rebuildCaches) {
-	// the iterator can only point into a fresh mirror (a stale one is empty)
+	// the iterator can only point into a fresh mirror (a stale one is empty inside the host-loop windows and refilled outside)
 	_mirror.deleteMolecule(moleculeIter, rebuildCaches);
 	_hostDirty = true;
 }
@@ -108,15 +108,55 @@ double LinkedCellsHip::getEnergy(ParticlePairsHandler* particlePairsHandler, Mol
 }
 
 std::variant<ParticleIterator, SingleCellIterator<ParticleCell>> LinkedCellsHip::getMoleculeAtPosition(const double pos[3]) {
-	if (!_mirrorFresh) syncMirrorFromDevice();
+	if (!_mirrorFresh) syncMirrorFromDevice();  // a point query has no per-step caller in the driver: always the real molecules
 	return _mirror.getMoleculeAtPosition(pos);
 }
 
-ParticleIterator LinkedCellsHip::iterator(ParticleIterator::Type t) { return _mirror.iterator(t); }
+// Who iterates a stale mirror?  Inside the two windows below it is the driver's own per-step host loops, whose work the device has
+// done (they must find nothing); anywhere else it is a consumer of the molecules — an end-of-step plugin (CheckpointWriter with a
+// write frequency, MmpldWriter, MaxCheck ...), the timed or final checkpoint (Simulation.cpp:1169-1175,1216-1225), a finishing
+// plugin — and it gets the real molecules: the mirror is refilled from the device ON DEMAND, never silently empty.
+//   window 1: eventNewTimestep ... eventForcesCalculated  (exchangeMolecules, updateForces / calcFM, Simulation.cpp:995-1099)
+//   window 2: eventForcesCalculated ... advanceSimulationTime  (VelocityScalingThermostat::apply, Simulation.cpp:1108-1136): the
+//             simulation time is still the one eventForcesCalculated saw
+bool LinkedCellsHip::inHostLoopWindow() {
+	if (_stepOpen) return true;
+	if (_quietArmed) {
+		if (global_simulation->getSimulationTime() == _quietTime) return true;
+		_quietArmed = false;  // the driver advanced the time: the step's host loops are over
+	}
+	return false;
+}
+
+void LinkedCellsHip::stepClosed() {
+	_stepOpen = false;
+	_quietArmed = true;
+	_quietTime = global_simulation->getSimulationTime();
+	_betaPending = !global_simulation->getDomain()->NVE();
+}
+
+void LinkedCellsHip::ensureMirror() {
+	if (_mirrorFresh || !_uploaded || inHostLoopWindow()) return;
+	// iterator() may be called by every thread of a parallel region at once (LinkedCells.h:245-250): one of them refills
+#if defined(_OPENMP)
+#pragma omp critical(ls1hip_mirror_sync)
+#endif
+	{
+		// past the thermostat's window: the scaling of the step just finished (VelocityScalingThermostat::apply, which found an
+		// empty mirror) is still pending on the device — it is folded into the next kick + drift pass — so the snapshot applies it
+		if (!_mirrorFresh) syncMirrorFromDevice(_betaPending);
+	}
+}
+
+ParticleIterator LinkedCellsHip::iterator(ParticleIterator::Type t) {
+	ensureMirror();
+	return _mirror.iterator(t);
+}
 
 RegionParticleIterator LinkedCellsHip::regionIterator(const double startCorner[3], const double endCorner[3],
 													   ParticleIterator::Type t) {
 	if (_inExchange) return RegionParticleIterator();  // DomainDecompBase::exchangeMolecules: done on the device
+	ensureMirror();
 	return _mirror.regionIterator(startCorner, endCorner, t);
 }
 
@@ -129,7 +169,10 @@ unsigned long LinkedCellsHip::getNumberOfParticles() {
 	return _mirror.getNumberOfParticles();
 }
 
-std::vector<unsigned long> LinkedCellsHip::getParticleCellStatistics() { return _mirror.getParticleCellStatistics(); }
+std::vector<unsigned long> LinkedCellsHip::getParticleCellStatistics() {
+	ensureMirror();
+	return _mirror.getParticleCellStatistics();
+}
 std::string LinkedCellsHip::getConfigurationAsString() { return _mirror.getConfigurationAsString() + " (device-resident, libls1hip)"; }
 size_t LinkedCellsHip::getTotalSize() { return _mirror.getTotalSize(); }
 void LinkedCellsHip::printSubInfo(int offset) { _mirror.printSubInfo(offset); }
@@ -263,14 +306,23 @@ void LinkedCellsHip::traversePartialInnermostCells(CellProcessor& cellProcessor,
 }
 
 void LinkedCellsHip::deviceAdvanced() {
+	_stepOpen = true;
+	_quietArmed = false;
+	_betaPending = false;  // (the integrator has just applied the factors on the device)
 	if (_mirrorFresh) {
 		_mirror.clear();  // stale from here on: its iterators stay valid and yield nothing
 		_mirrorFresh = false;
 	}
 }
 
-void LinkedCellsHip::syncMirrorFromDevice() {
+void LinkedCellsHip::syncMirrorFromDevice(bool applyPendingBeta) {
 	if (!_uploaded) return;
+	double betaTrans = 1., betaRot = 1.;
+	if (applyPendingBeta) {  // global thermostat only (component-wise ones are rejected by the integrator)
+		Domain* domain = global_simulation->getDomain();
+		betaTrans = domain->getGlobalBetaTrans();
+		betaRot = domain->getGlobalBetaRot();
+	}
 	size_t n = 0, h = 0;
 	ls1hip_count(_ctx, &n, &h);
 	std::vector<uint64_t> id(n);
@@ -284,8 +336,9 @@ void LinkedCellsHip::syncMirrorFromDevice() {
 	std::vector<Molecule> mols;
 	mols.reserve(n);
 	for (size_t i = 0; i < n; ++i) {
-		Molecule m(id[i], &comps[cid[i]], r[3 * i], r[3 * i + 1], r[3 * i + 2], v[3 * i], v[3 * i + 1], v[3 * i + 2], q[4 * i],
-				   q[4 * i + 1], q[4 * i + 2], q[4 * i + 3], D[3 * i], D[3 * i + 1], D[3 * i + 2]);
+		Molecule m(id[i], &comps[cid[i]], r[3 * i], r[3 * i + 1], r[3 * i + 2], betaTrans * v[3 * i], betaTrans * v[3 * i + 1],
+				   betaTrans * v[3 * i + 2], q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3], betaRot * D[3 * i],
+				   betaRot * D[3 * i + 1], betaRot * D[3 * i + 2]);
 		if (haveF) {
 			m.setF(&F[3 * i]);
 			m.setM(&M[3 * i]);
@@ -361,11 +414,13 @@ void LeapfrogHip::eventForcesCalculated(ParticleContainer* moleculeContainer, Do
 	_haveBeta = true;
 	_state = STATE_POST_FORCE_CALCULATION;
 	++_stepsDone;
-	// lazily synced mirror: after the last step (final checkpoint, finishing plugins) and every N steps on request
+	cont->stepClosed();
+	// lazily synced mirror: whoever iterates the container outside the driver's per-step host loops gets it refilled on demand
+	// (LinkedCellsHip::ensureMirror); LS1HIP_MIRROR_SYNC_INTERVAL additionally refills every N steps
 	long interval = 0;
 	if (const char* e = getenv("LS1HIP_MIRROR_SYNC_INTERVAL")) interval = atol(e);
 	Simulation* sim = global_simulation;
-	bool last = sim->getSimulationStep() >= sim->getNumTimesteps();
+	const bool last = sim->getSimulationStep() >= sim->getNumTimesteps();
 	if (last) {
 		long on = 0, builds = 0, evals = 0;
 		ls1hip_get_option(ctx, "verlet_lists", &on);
@@ -374,7 +429,5 @@ void LeapfrogHip::eventForcesCalculated(ParticleContainer* moleculeContainer, Do
 		global_log->info() << "LinkedCellsHip: neighbour lists " << (on ? "on" : "off") << ": " << builds << " builds for " << evals
 						   << " list force evaluations" << std::endl;
 	}
-	if (const char* e = getenv("LS1HIP_MIRROR_SYNC_FINAL"))  // "0": nothing will iterate the molecules after the run (no final
-		if (atoi(e) == 0) last = false;                      // checkpoint, no finishing plugin): skip the O(N) host refill
-	if (last || (interval > 0 && _stepsDone % (unsigned long)interval == 0)) cont->syncMirrorFromDevice();
+	if (interval > 0 && _stepsDone % (unsigned long)interval == 0) cont->syncMirrorFromDevice();
 }

@@ -20,9 +20,10 @@
 // loops — Simulation::updateForces (calcFM), DomainDecompBase::exchangeMolecules, VelocityScalingThermostat::apply — into
 // no-ops without touching them: their work happens on the device (site reduction inside the force kernels, periodic
 // wrap + halo copies in ls1hip_rebin / ls1hip_halo, velocity scaling by the beta factors the driver's own
-// Domain::calculateGlobalValues computed).  The mirror is refilled from the device (lazily synced, read-only snapshot)
-// after the last time step and every LS1HIP_MIRROR_SYNC_INTERVAL steps, so that end-of-step plugins, result writers and
-// the final checkpoint iterate real molecules.
+// Domain::calculateGlobalValues computed).  OUTSIDE those per-step windows (eventNewTimestep .. advanceSimulationTime) a reader
+// of the stale mirror — end-of-step plugins such as CheckpointWriter, the timed / final checkpoint, finishing plugins — makes
+// the container refill it from the device first (lazily synced ON DEMAND, read-only snapshot): such a reader never sees an
+// empty container.
 #pragma once
 #include <array>
 #include <string>
@@ -88,8 +89,11 @@ public:
 	ls1hip_ctx* context() { return _ctx; }
 	bool deviceReady() const { return _uploaded; }
 	void deviceAdvanced();            // the integrator moved the molecules on the device: the mirror is stale -> emptied
-	void syncMirrorFromDevice();      // refill the mirror with the device state (read-only snapshot for plugins / writers)
+	// refill the mirror with the device state (read-only snapshot for plugins / writers); applyPendingBeta: with the velocity
+	// scaling of the finished step applied, which the device folds into its next kick + drift pass
+	void syncMirrorFromDevice(bool applyPendingBeta = false);
 	bool mirrorFresh() const { return _mirrorFresh; }
+	void stepClosed();                // eventForcesCalculated is through: only the thermostat's host loop follows in this step
 	void armPostForceKick(double dt_half) { _armedKick = dt_half; }  // the next complete traversal queues the kick behind itself
 	bool takeQueuedKick() {
 		const bool q = _kickQueued;
@@ -99,6 +103,8 @@ public:
 
 private:
 	void die(const char* what, int rc) const;
+	bool inHostLoopWindow();          // the driver's per-step host loops (device did their work): a stale mirror stays empty
+	void ensureMirror();              // any other reader of a stale mirror: refill from the device first
 	void uploadFromMirror();
 	void deviceForces(int which);
 
@@ -111,6 +117,10 @@ private:
 	bool _mirrorFresh = true;   // the mirror holds the current molecule set
 	bool _hostDirty = true;     // molecules were added / removed through the host interface since the last upload
 	bool _inExchange = false;   // between update() and updateMoleculeCaches(): the driver's exchangeMolecules window
+	bool _stepOpen = false;     // between eventNewTimestep and eventForcesCalculated
+	bool _quietArmed = false;   // after eventForcesCalculated until the driver advances the simulation time (thermostat loop)
+	double _quietTime = 0.;
+	bool _betaPending = false;  // thermostat factors of the finished step not yet applied on the device
 };
 
 class LeapfrogHip : public Integrator {

@@ -26,7 +26,10 @@ MAN = manifest()
 
 
 def _production_engine(name, skin=0.2, **opts):
-    case = MAN[name]
+    return _production_engine_case(MAN[name], skin, **opts)
+
+
+def _production_engine_case(case, skin=0.2, **opts):
     ps = inp.read_inp(input_path(case["input"]))
     st = sorted_phase_space(ps)
     e = engine_mod.DeviceEngine(0)
@@ -187,3 +190,58 @@ def test_headline_box_1e8_list_loop_equals_per_step_loop():
     for col, what in ((0, "upot"), (1, "virial"), (2, "summv2")):
         err = np.max(np.abs(a[:, col] - b[:, col]) / np.abs(a[:, col]))
         assert err < 1e-12, (what, err)
+
+
+# ---- the reference's single-precision build modes ---------------------------------------------------------
+SP = manifest(single_precision=True)
+
+
+@pytest.mark.parametrize("name", [k for k, c in SP.items() if c["steps"] == 0])
+def test_single_precision_list_pass_against_reference_sp_build(name):
+    """"precision" = 1 (SPDP) / 2 (SPSP) of the list force pass against golden vectors of the REAL reference built with
+    -DMARDYN_SPDP / -DMARDYN_SPSP (oracle/ref_build `make spdp spsp`; cmake/modules/options.cmake:13-15,
+    vectorization/SIMD_TYPES.h:28-36, RealAccumVecSPDP.h), non-forced production configuration, regular bricks only.
+    Tolerances are single-precision ones, set from the reference's own SP-vs-FP64 deviation on this box (forces 1.9e-5 of
+    max|F|, U_pot 3e-8, virial 3e-8: the reference rounds ABSOLUTE coordinates to FP32, this pass region-relative ones, so it
+    must lie at least as close to the FP64 golden as the reference's SP build does)."""
+    case = SP[name]
+    g, dp = read_golden(name), read_golden("bcc1clj_8192")
+    _, ps, st, e = _production_engine_case(case, 0.2, precision=case["precision"])
+    assert e.update() is True
+    u, w = e.forces_list(0, 0.0, want_macro=True)
+    _assert_production_path(e)
+    assert e.get_option("precision_in_use") == case["precision"]
+    ids, r, v, F = _sorted(e)
+    assert np.array_equal(ids, g["recs"]["id"])
+    assert rel_max(F, g["recs"]["F"]) < 5e-5
+    assert abs(u - g["upot"]) <= 2e-7 * abs(g["upot"]) and abs(w - g["virial"]) <= 2e-7 * abs(g["virial"])
+    ref_dev = rel_max(g["recs"]["F"], dp["recs"]["F"])
+    assert rel_max(F, dp["recs"]["F"]) <= ref_dev
+    assert abs(u - dp["upot"]) <= 1e-7 * abs(dp["upot"]) and abs(w - dp["virial"]) <= 1e-7 * abs(dp["virial"])
+    e.close()
+
+
+@pytest.mark.parametrize("name", [k for k, c in SP.items() if c["steps"] > 0])
+def test_single_precision_list_loop_against_reference_sp_trajectory(name):
+    """10 Leapfrog steps of the reference's SPDP / SPSP builds through ls1hip_run's list loop in the same precision mode."""
+    case = SP[name]
+    g = read_golden(name)
+    _, ps, st, e = _production_engine_case(case, 0.2, precision=case["precision"])
+    e.rebin(); e.halo(); e.forces(0)
+    out = e.run(case["dt"], case["steps"])
+    _assert_production_path(e)
+    assert e.get_option("precision_in_use") == case["precision"] and e.get_option("verlet_builds") >= 2
+    ids, r, v, F = _sorted(e)
+    rec = g["recs"]
+    L = ps.length
+    dr = r - rec["r"]
+    dr -= L * np.round(dr / L)
+    assert np.max(np.abs(dr)) < 1e-7 * np.max(L)
+    # (FP32 pair arithmetic on differently rounded coordinates — absolute in the reference, region-relative here — over 10 steps:
+    # measured 5.6e-5 of max|v|; the reference's own SPDP and SPSP trajectories differ by 4e-7, its SP and FP64 forces by 2e-5)
+    assert rel_max(v, rec["v"]) < 2e-4
+    assert rel_max(F, rec["F"]) < 5e-4
+    assert abs(out["upot"] - g["upot"]) <= 1e-6 * abs(g["upot"])
+    assert abs(out["virial"] - g["virial"]) <= 5e-6 * abs(g["virial"])
+    assert abs(out["summv2"] - g["summv2"]) <= 1e-6 * abs(g["summv2"])
+    e.close()

@@ -133,3 +133,38 @@ def test_device_container_speed_line_in_the_reference_driver(tmp_path):
         del os.environ["LS1HIP_MIRROR_SYNC_FINAL"]
         os.environ.pop("LS1HIP_SKIN", None)
     assert np.allclose(res["default"][0], res["0"][0], rtol=2e-5, atol=1e-12)  # same printed T / U_pot / p either way
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(HIPB)), reason="oracle/_ref binaries not built")
+def test_end_of_step_plugin_sees_the_molecules_of_the_device_container(tmp_path):
+    """a reader of the container outside the driver's per-step host loops must never find it empty.
+    The reference's own CheckpointWriter with writefrequency 5 (io/CheckpointWriter.cpp:62: iterates the container in
+    endStep) under the unmodified driver with the device container: every INTERMEDIATE checkpoint (steps 5, 10, 15) must hold
+    the molecules the unmodified reference binary wrote at that step — the mirror is refilled from the device on demand."""
+    N = 2 * 20 ** 3
+    L = (N / 0.785302672) ** (1 / 3)
+    plugin = ('<output><outputplugin name="CheckpointWriter"><type>ASCII</type><writefrequency>5</writefrequency>'
+              '<outputprefix>cp</outputprefix></outputplugin></output>')
+    cfg = HEAD.format(dt=0.002, steps=15, temp=0.95, L=repr(L), rc=2.5, components=LJ1,
+                      phasespace='<generator name="CubicGridGenerator"><specification>density</specification>'
+                                 '<density>0.785302672</density><binaryMixture>false</binaryMixture></generator>')
+    cfg = cfg.replace("<output></output>", plugin)
+    files = {}
+    for tag, binary in (("ref", REF), ("hipB", HIPB)):
+        d = tmp_path / tag
+        d.mkdir()
+        (d / "config.xml").write_text(cfg)
+        rows, log = _run(binary, "config.xml", str(d), 15, final_checkpoint=0)
+        files[tag] = {f: _restart_records(d / f) for f in sorted(os.listdir(d)) if f.startswith("cp-") and f.endswith(".restart.dat")}
+        files[tag + "_rows"] = rows
+    assert len(files["ref"]) >= 3 and files["ref"].keys() == files["hipB"].keys(), (list(files["ref"]), list(files["hipB"]))
+    assert np.allclose(files["hipB_rows"][:15], files["ref_rows"][:15], rtol=2e-5, atol=1e-12)
+    for f in files["ref"]:
+        a, b = files["ref"][f], files["hipB"][f]
+        assert len(a) == N and a.keys() == b.keys(), (f, len(a), len(b))
+        ids = sorted(a)
+        A, B = np.array([a[i] for i in ids]), np.array([b[i] for i in ids])
+        dr = A[:, :3] - B[:, :3]
+        dr -= L * np.round(dr / L)
+        assert np.max(np.abs(dr)) < 1e-7 * L, f
+        assert np.max(np.abs(A[:, 3:6] - B[:, 3:6])) < 1e-6 * np.max(np.abs(A[:, 3:6])), f

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Builds a VARIANT of libls1hip.so for same-box A/B timing runs: tools/ab_variant.sh <tag> "<extra hipcc flags>" [file.hip ...]
+# The named sources (default: csrc/kernels_force_verlet.hip) are recompiled with the extra flags, everything else is taken from
+# the regular build; output: ls1-mardyn_amd/lib/variants/libls1hip_<tag>.so (git-ignored, travels with gpurun).
+# Use: LS1HIP_LIB=ls1-mardyn_amd/lib/variants/libls1hip_<tag>.so python bench.py ...
+set -e
+tag=$1; flags=$2; shift 2 || true
+files=${@:-csrc/kernels_force_verlet.hip}
+cd "$(dirname "$0")/../ls1-mardyn_amd"
+make -s -j4
+mkdir -p build_$tag lib/variants
+objs=""
+for o in build/*.o; do
+  b=$(basename $o .o)
+  if echo " $files " | grep -q "csrc/$b.hip"; then
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function -Wno-unused-result -Wno-unused-value $flags -c csrc/$b.hip -o build_$tag/$b.o
+    objs="$objs build_$tag/$b.o"
+  else
+    objs="$objs $o"
+  fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o lib/variants/libls1hip_$tag.so
+echo "built lib/variants/libls1hip_$tag.so"

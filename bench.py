@@ -38,6 +38,7 @@ FORCE_BYTES_PER_MOLECULE = 48.0   # read r (24 B) + write F (24 B): SURVEY.md 8(
 FUSED_BYTES_PER_MOLECULE = 96.0
 PMC_SUMMARY = "r2_pmc_summary.json"  # rocprofv3 PMC passes of this workload (tools/collect_profiles.sh)
 STEP_BYTES_PER_MOLECULE = 292.0   # full step: force 48 + integrator 120 + re-bin 124
+MS_FORCE_BYTES_PER_MOLECULE = 104.0  # multi-site force pass: read r 24 + q 32, write F 24 + M 24
 HBM_PEAK_GBS = 8000.0
 BASELINE_METRIC = "particle-updates/sec (whole node), 10^8 LJ liquid Argon, rc=2.5\u03c3"  # BASELINE.json, verbatim
 
@@ -86,33 +87,110 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(n_per_dim=171, steps=10, budget_s=150):
-    """Reference OpenMP CPU path on the host cores: same liquid (bcc lattice start from the reference's own
-    CubicGridGenerator), bounded sample N = 2*n^3, `steps` steps."""
-    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("LS1_BENCH_CPU_THREADS", "16")))
-    N = 2 * n_per_dim ** 3
-    L = (N / RHO) ** (1.0 / 3.0)
-    binary = os.path.join(ROOT, "oracle", "_ref", "MarDyn")
-    if os.path.exists(binary):
-        with tempfile.TemporaryDirectory() as td:
-            cfg = os.path.join(td, "config.xml")
-            with open(cfg, "w") as fh:
-                fh.write(MARDYN_XML.format(dt=DT, steps=steps, temp=TEMP, L=repr(L), rho=RHO, rc=RC))
-            env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="close", OMP_PLACES="cores")
+def cpu_share():
+    """(threads to use, description): the CPUs this process may really use — the cgroup CPU quota where one is set
+    (cpu.max / cfs_quota), else the affinity mask counted in physical cores (one thread per core: the reference's
+    vectorised kernels do not gain from SMT siblings)."""
+    vis = len(os.sched_getaffinity(0))
+    quota = None
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else float(t.split()[0]) / float(t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            txt = open(path).read().strip()
+            if parse:
+                quota = parse(txt)
+            else:
+                q = float(txt)
+                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip())
+                quota = q / per if q > 0 else None
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    smt = 1
+    try:
+        sib = open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list").read().strip()
+        smt = max(1, len(sib.replace("-", ",").split(",")))
+    except OSError:
+        pass
+    phys = max(1, vis // smt)
+    env = os.environ.get("LS1_BENCH_CPU_THREADS")
+    if env:
+        return max(1, int(env)), {"visible_cpus": vis, "cgroup_quota_cpus": quota, "physical_cores_visible": phys, "threads_from": "LS1_BENCH_CPU_THREADS"}
+    if quota:
+        n = max(1, min(phys, int(quota + 0.5)))
+        src = "cgroup cpu quota"
+    else:
+        # no quota: the GPU pool gives one GPU's share of the host (16 CPUs per GPU: gpurun's sizing rule) — use it, not all
+        # 128 cores of a box whose other seven GPUs belong to other jobs
+        n = min(phys, int(os.environ.get("LS1_BENCH_CPU_SHARE", "16")))
+        src = "one GPU's share of the host (16 CPUs per GPU on this pool; LS1_BENCH_CPU_SHARE overrides)"
+    return n, {"visible_cpus": vis, "cgroup_quota_cpus": quota, "physical_cores_visible": phys, "threads_from": src}
+
+
+def _run_reference(binary, cfg_text, steps, cores, budget_s, extra_files=None):
+    with tempfile.TemporaryDirectory() as td:
+        cfg = os.path.join(td, "config.xml")
+        with open(cfg, "w") as fh:
+            fh.write(cfg_text)
+        for name, writer in (extra_files or {}).items():
+            writer(os.path.join(td, name))
+        env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="close", OMP_PLACES="cores")
+        try:
+            out = subprocess.run([binary, cfg, "--steps", str(steps), "--final-checkpoint=0"], cwd=td, env=env,
+                                 capture_output=True, text=True, timeout=budget_s).stdout
+        except subprocess.TimeoutExpired:
+            return None, None
+        m = re.search(r"Simulation speed:\s*([0-9.eE+-]+)\s*Molecule-updates per second", out)
+        nm = re.search(r"[Nn]umber of molecules[^0-9]*([0-9]+)", out)
+        return (float(m.group(1)) if m else None), (nm.group(1) if nm else None)
+
+
+def cpu_baseline(n_per_dim=171, steps=10, budget_s=150, workload="lj"):
+    """Reference OpenMP CPU path on the host cores this job may use: the REAL reference binary, built twice by
+    oracle/ref_build (AVX2 = the reference's portable vector mode, and -march=x86-64-v4 = its AVX-512 kernels, the
+    VECTOR_INSTRUCTIONS=NATIVE class of an AVX-512 host); the faster of the two is reported, the other one next to it.
+    Sample (bounded, ~10-30 s of CPU work): lj = configs[1] (N = 2*171^3 from the reference's own CubicGridGenerator);
+    ethane = the reference's equilibrated ethane box replicated 6^3 (binary checkpoint written by inp.write_checkpoint)."""
+    cores, share = cpu_share()
+    inp = importlib.import_module("ls1-mardyn_amd.inp")
+    builds = [("AVX2", os.path.join(ROOT, "oracle", "_ref", "MarDyn")), ("AVX-512 (-march=x86-64-v4)", os.path.join(ROOT, "oracle", "_ref", "MarDyn_avx512"))]
+    extra = None
+    if workload == "ethane":
+        ps, comps_xml = ethane_fixture(inp)
+        k = 6
+        big = replicate_phase_space(inp, ps, k)
+        L = float(big.length[0])
+        cfg = ETHANE_XML.format(dt=ETHANE_DT, steps=steps, temp=repr(ps.temperature), L=repr(L), rc=ETHANE_RC)
+        extra = {"eth.header.xml": lambda path, big=big: inp.write_checkpoint(path[:-len(".header.xml")], big)}
+        what = f"2CLJ ethane, the reference's Ethan_equilibrated box replicated {k}^3 = {len(big.ids)} molecules, rc={ETHANE_RC}"
+    else:
+        N = 2 * n_per_dim ** 3
+        L = (N / RHO) ** (1.0 / 3.0)
+        cfg = MARDYN_XML.format(dt=DT, steps=steps, temp=TEMP, L=repr(L), rho=RHO, rc=RC)
+        what = f"1CLJ N={N} bcc rho*={RHO} rc={RC}"
+    results = {}
+    nmol = None
+    for tag, binary in builds:
+        if not os.path.exists(binary):
+            continue
+        # an AVX-512 build on a host without AVX-512 would die with SIGILL: ask the CPU first
+        if "512" in tag:
             try:
-                out = subprocess.run([binary, cfg, "--steps", str(steps), "--final-checkpoint=0"], cwd=td, env=env,
-                                     capture_output=True, text=True, timeout=budget_s).stdout
-            except subprocess.TimeoutExpired:
-                out = ""
-            m = re.search(r"Simulation speed:\s*([0-9.eE+-]+)\s*Molecule-updates per second", out)
-            nm = re.search(r"[Nn]umber of molecules[^0-9]*([0-9]+)", out)
-            if m:
-                return {"value": float(m.group(1)), "unit": "particle-updates/s", "cores": cores, "kind": "reference",
-                        "cpu": cpu_model(), "host_cpus_visible": len(os.sched_getaffinity(0)),
-                        "sample": f"reference MarDyn (AVX2, OpenMP c08, FP64) 1CLJ N={nm.group(1) if nm else N} bcc rho*={RHO} rc={RC}, {steps} steps, {cores} threads"}
+                if "avx512f" not in open("/proc/cpuinfo").read():
+                    continue
+            except OSError:
+                continue
+        v, nm = _run_reference(binary, cfg, steps, cores, budget_s, extra)
+        if v:
+            results[tag] = v
+            nmol = nmol or nm
+    if results:
+        best = max(results, key=results.get)
+        return {"value": results[best], "unit": "particle-updates/s", "cores": cores, "kind": "reference", "cpu": cpu_model(),
+                "cpu_share": share, "build": best, "all_builds": results,
+                "sample": f"reference MarDyn ({best}, OpenMP c08, FP64) {what}{' (N=' + nmol + ')' if nmol else ''}, {steps} steps, {cores} threads"}
     # fallback: the oracle restatement (scalar, 1 core) — only when the reference binary did not travel
     from oracle.oracle import Oracle  # checker, used here only as the timed CPU baseline
-    inp = importlib.import_module("ls1-mardyn_amd.inp")
     Lb, _ids, r, v = importlib.import_module("ls1-mardyn_amd.synth").bcc_box(20, rho=RHO, temp=TEMP)
     n = len(r)
     orc = Oracle(lj_components(inp).flat(), RC)
@@ -128,13 +206,104 @@ def cpu_baseline(n_per_dim=171, steps=10, budget_s=150):
             "sample": f"oracle/ls1_oracle.c scalar restatement, 1CLJ N={n}, {ksteps} steps, 1 thread"}
 
 
-def live_pmc_traffic(argv_tail, budget_s=240):
-    """HBM traffic of the dominant force kernel measured LIVE: two short child runs of this script under
-    `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace` (separate passes, no other trace domain — the recipe of
-    MI355X_MICROARCH.md), per-launch means, with the guide's gfx950 corrections: both counters are reported in KB and
-    FETCH_SIZE counts half of the bytes of 8 B/lane reads (x2; calibrated in profiles/ on a kernel of known traffic).
-    Returns (bytes per launch, kernel name) or (None, reason).  The children are separate processes started BEFORE they
-    touch the GPU (no exec from a GPU-initialised process)."""
+# ---- multi-site workloads (BASELINE.json configs[3] / configs[4]) ----------------------------------------------------------
+ETHANE_RC = 32.1254   # cutoff of the reference's own ethane test (tests/golden MANIFEST, VectorizedCellProcessorTest)
+ETHANE_DT = 0.5
+MIXED_RC = 35.0
+ETHANE_XML = """<?xml version='1.0' encoding='UTF-8'?>
+<mardyn version="20100525">
+  <refunits type="SI"><length unit="nm">0.1</length><mass unit="u">1</mass><energy unit="K">1</energy></refunits>
+  <simulation type="MD">
+    <integrator type="Leapfrog"><timestep unit="reduced">{dt}</timestep></integrator>
+    <run><currenttime>0</currenttime><production><steps>{steps}</steps></production></run>
+    <ensemble type="NVT">
+      <temperature unit="reduced">{temp}</temperature>
+      <domain type="box"><lx>{L}</lx><ly>{L}</ly><lz>{L}</lz></domain>
+      <components>
+        <moleculetype id="1" name="C2H6">
+          <site type="LJ126" id="1"><coords><x>0.0</x><y>0.0</y><z>-2.2157048</z></coords><mass>0.0150347</mass><sigma>6.6140441</sigma><epsilon>0.00042932536</epsilon><shifted>0</shifted></site>
+          <site type="LJ126" id="2"><coords><x>0.0</x><y>0.0</y><z>2.2157048</z></coords><mass>0.0150347</mass><sigma>6.6140441</sigma><epsilon>0.00042932536</epsilon><shifted>0</shifted></site>
+          <momentsofinertia rotaxes="xyz"><Ixx>0.14762114</Ixx><Iyy>0.14762114</Iyy><Izz>0.0</Izz></momentsofinertia>
+        </moleculetype>
+      </components>
+      <phasespacepoint><file type="binary"><header>eth.header.xml</header><data>eth.dat</data></file></phasespacepoint>
+    </ensemble>
+    <algorithm>
+      <parallelisation type="DomainDecomposition"></parallelisation>
+      <datastructure type="LinkedCells"><cellsInCutoffRadius>1</cellsInCutoffRadius></datastructure>
+      <cutoffs type="CenterOfMass"><radiusLJ unit="reduced">{rc}</radiusLJ></cutoffs>
+      <electrostatic type="ReactionField"><epsilon>1.0e+10</epsilon></electrostatic>
+    </algorithm>
+    <output></output>
+  </simulation>
+</mardyn>
+"""
+
+
+def _fixture(name):
+    """a reference test input kept as a fixture under tests/golden/inputs (plain or gzip)"""
+    import gzip
+    import shutil
+    p = os.path.join(ROOT, "tests", "golden", "inputs", name)
+    if os.path.exists(p):
+        return p
+    tmp = os.path.join(tempfile.gettempdir(), "ls1bench_" + name)
+    if not os.path.exists(tmp):
+        with gzip.open(p + ".gz", "rb") as fi, open(tmp + ".part", "wb") as fo:
+            shutil.copyfileobj(fi, fo)
+        os.replace(tmp + ".part", tmp)
+    return tmp
+
+
+def ethane_fixture(inp):
+    ps = inp.read_inp(_fixture("Ethan_equilibrated.inp"))
+    return ps, None
+
+
+def replicate_phase_space(inp, ps, k):
+    """k x k x k periodic replication (what the reference's io/ReplicaGenerator.cpp does for its large multi-site boxes)"""
+    n0 = len(ps.ids)
+    shifts = np.array([[i, j, l] for i in range(k) for j in range(k) for l in range(k)], dtype=float) * ps.length
+    r = (ps.r[None, :, :] + shifts[:, None, :]).reshape(-1, 3)
+    t = lambda a: np.tile(a, (k ** 3,) + (1,) * (a.ndim - 1))  # noqa: E731
+    q = ps.q / np.linalg.norm(ps.q, axis=1, keepdims=True)
+    return inp.PhaseSpace(ps.components, ps.length * k, np.arange(1, n0 * k ** 3 + 1, dtype=np.uint64), t(ps.cid), r, t(ps.v), t(q),
+                          t(ps.D), ps.time, ps.temperature)
+
+
+def mixed_box(inp, n):
+    """configs[4]: the five components of VectorizationMultiComponentMultiPotentials.inp on a jittered bcc
+    lattice at the fixture's number density, component = id mod 5, hash quaternions.  Two of the five components carry no
+    mass in the reference's fixture (pure dipole / dipole + quadrupole sites): the set cannot be integrated, by the reference
+    either — this workload is a force-traversal workload."""
+    ps0 = inp.read_inp(_fixture("VectorizationMultiComponentMultiPotentials.inp"))
+    comps = ps0.components
+    rng = np.random.default_rng(11)
+    n0 = 2 * n ** 3
+    rho = 250.0 / 134.266123 ** 3
+    L = (n0 / rho) ** (1.0 / 3.0)
+    a = L / n
+    g = np.arange(n)
+    gpts = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3) * a
+    r = np.concatenate([gpts + 0.25 * a, gpts + 0.75 * a])
+    r = (r + 0.2 * a * rng.uniform(-0.5, 0.5, r.shape)) % L
+    q = rng.normal(size=(n0, 4))
+    q /= np.linalg.norm(q, axis=1)[:, None]
+    cid = (np.arange(n0) % len(comps.components)).astype(np.int32)
+    return comps, L, np.arange(1, n0 + 1, dtype=np.uint64), cid, r, q
+
+
+PMC_TRAFFIC = (("FETCH_SIZE",), ("WRITE_SIZE",))
+PMC_COMPUTE = (("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_WAVES", "GRBM_GUI_ACTIVE"),
+               ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64",
+                "GRBM_GUI_ACTIVE"))
+
+
+def live_pmc(argv_tail, groups, budget_s=300):
+    """Hardware counters of the dominant force kernel measured LIVE: one short child run of this script per counter group
+    under `rocprofv3 --pmc <group> --kernel-trace` (separate passes, no other trace domain — the recipe of
+    MI355X_MICROARCH.md), per-launch means.  Returns ({counter: mean per launch}, kernel name) or (None, reason).  The
+    children are separate processes started BEFORE they touch the GPU (no exec from a GPU-initialised process)."""
     import csv
     import glob
     import shutil
@@ -145,38 +314,70 @@ def live_pmc_traffic(argv_tail, budget_s=240):
         return None, "this run is itself being profiled (no nested profiler)"
     per = {}
     kernel = None
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for group in groups:
         td = tempfile.mkdtemp(prefix="ls1pmc_", dir="/tmp")
         try:
-            cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", td, "--", sys.executable,
-                   os.path.join(ROOT, "bench.py"), "--pmc-child"] + argv_tail
+            cmd = [prof, "--pmc"] + list(group) + ["--kernel-trace", "--output-format", "csv", "-d", td, "--", sys.executable,
+                                                   os.path.join(ROOT, "bench.py"), "--pmc-child"] + argv_tail
             env = dict(os.environ, TMPDIR="/tmp")
             res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=budget_s)
             files = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
             if res.returncode != 0 or not files:
-                return None, f"rocprofv3 pass {counter} failed (rc {res.returncode})"
+                return None, f"rocprofv3 pass {group[0]} failed (rc {res.returncode})"
             acc = {}
             for f in files:
                 with open(f) as fh:
                     for r in csv.DictReader(fh):
-                        if r.get("Counter_Name") != counter:
-                            continue
                         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
                         if "k_force_" in name and "reduce" not in name:
-                            acc.setdefault(name, []).append(float(r["Counter_Value"]))
+                            acc.setdefault(name, {}).setdefault(r.get("Counter_Name"), []).append(float(r["Counter_Value"]))
             if not acc:
                 return None, "no force kernel in the counter trace"
             # dominant force kernel = most launches (the list build / first-step kernels appear once or a few times)
-            name = max(acc, key=lambda k: len(acc[k]))
+            name = max(acc, key=lambda k: max(len(v) for v in acc[k].values()))
             kernel = kernel or name
             if name != kernel:
-                return None, "the two passes disagree on the dominant kernel"
-            per[counter] = sum(acc[name]) / len(acc[name])
+                return None, "the passes disagree on the dominant kernel"
+            for cname, vals in acc[name].items():
+                per[cname] = sum(vals) / len(vals)
         except subprocess.TimeoutExpired:
-            return None, f"rocprofv3 pass {counter} exceeded {budget_s} s"
+            return None, f"rocprofv3 pass {group[0]} exceeded {budget_s} s"
         finally:
             shutil.rmtree(td, ignore_errors=True)
+    return per, kernel
+
+
+def live_pmc_traffic(argv_tail, budget_s=300):
+    """HBM traffic per launch with the guide's gfx950 corrections: both counters are reported in KB and FETCH_SIZE counts
+    half of the bytes of 8 B/lane reads (x2; calibrated in profiles/ on a kernel of known traffic)."""
+    per, kernel = live_pmc(argv_tail, PMC_TRAFFIC, budget_s)
+    if per is None:
+        return None, kernel
     return 2.0 * per["FETCH_SIZE"] * 1024.0 + per["WRITE_SIZE"] * 1024.0, kernel
+
+
+def live_pmc_compute(argv_tail, avg_launch_s, budget_s=300):
+    """VALU / LDS utilisation and the FP64 vector rate of the dominant force kernel from live counter passes (formulas of
+    tools/pmc_summarize.py: SQ_* cycle counters in quad-cycles, GRBM_GUI_ACTIVE summed over the 8 XCDs)."""
+    per, kernel = live_pmc(argv_tail, PMC_COMPUTE, budget_s)
+    if per is None:
+        return None, kernel
+    out = {"fp64_vector_peak_tflops": 78.6, "source": f"live: rocprofv3 --pmc child passes of this run, kernel {kernel}"}
+    cyc = per.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+    flop = 64.0 * (2.0 * per.get("SQ_INSTS_VALU_FMA_F64", 0.0) + per.get("SQ_INSTS_VALU_ADD_F64", 0.0) + per.get("SQ_INSTS_VALU_MUL_F64", 0.0))
+    out["fp64_flop_per_launch"] = flop
+    out["fp64_tflops"] = flop / avg_launch_s / 1e12
+    out["fp64_frac"] = out["fp64_tflops"] / 78.6
+    if cyc > 0:
+        out["kernel_cycles_under_profiler"] = cyc
+        if "SQ_ACTIVE_INST_VALU" in per:
+            out["valu_busy_frac_per_simd"] = per["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc)
+        if "SQ_LDS_IDX_ACTIVE" in per:
+            out["lds_busy_frac_per_cu"] = per["SQ_LDS_IDX_ACTIVE"] / (256.0 * cyc)
+            out["lds_bank_conflict_frac"] = per.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(per["SQ_LDS_IDX_ACTIVE"], 1.0)
+    if "SQ_INSTS_VALU" in per:
+        out["valu_wave_insts_per_launch"] = per["SQ_INSTS_VALU"]
+    return out, kernel
 
 
 def main():
@@ -209,10 +410,28 @@ def main():
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="skip the two short rocprofv3 --pmc child passes that measure roofline.traffic live (the figure "
                          "of the committed profiles/ summary is reported instead)")
+    ap.add_argument("--workload", choices=("lj", "ethane", "mixed"), default="lj",
+                    help="lj = the metric's 1CLJ liquid (default); ethane = BASELINE configs[3]: the reference's equilibrated 2CLJ "
+                         "ethane box replicated 10^3 = 9 826 000 molecules, full NVE step; mixed = configs[4]: the five-component LJ + "
+                         "charge + dipole + quadrupole set on the 171^3 bcc lattice (10 000 422 molecules), force traversals only "
+                         "(two of its components are massless in the reference's fixture: no integration possible)")
+    ap.add_argument("--melt", type=int, default=-1,
+                    help="untimed device steps BEFORE the warm-up steps (lj workload: default 200 — the lattice start melts, list "
+                         "lengths spread; the timed window is then steady state)")
+    ap.add_argument("--rebuild-every", type=int, default=10,
+                    help="mixed workload (static configuration): the lists are rebuilt every this many traversals, the interval the "
+                         "moving workloads measure")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.melt < 0:
+        args.melt = 200 if (args.workload == "lj" and args.gpus == 1 and not args.decomp) else 0
     if args.pmc_child:  # a counter pass: the same workload, a few steps, nothing else
         args.steps, args.warmup, args.no_cpu_baseline, args.no_live_pmc = 6, 2, True, True
+    if args.workload != "lj":
+        if args.gpus != 1 or args.decomp:
+            sys.exit("bench.py --workload ethane|mixed runs on one GPU (multi-site lists serve single-rank domains)")
+        if args.skin == 0.2:  # the default is in sigma of the LJ liquid; multi-site boxes are in atomic units
+            args.skin = {"ethane": 5.0, "mixed": 3.0}[args.workload]
 
     # stdout carries ONE JSON line: libraries that print to file descriptor 1 (RCCL prints a version banner when the first
     # communicator is created) are sent to stderr for the duration of the run; the result goes to the saved descriptor
@@ -258,7 +477,7 @@ def main():
         n_total = sim.n_global
         if args.loopback:  # rehearse the count exchange too (skipped otherwise when there is a single rank)
             sim.ex.force_count_exchange = True
-    else:
+    elif args.workload == "lj":
         engine_mod = importlib.import_module("ls1-mardyn_amd.engine")
         synth = importlib.import_module("ls1-mardyn_amd.synth")
         L = synth.box_length(n, RHO)
@@ -285,7 +504,30 @@ def main():
         eng.rebin(); eng.halo(); eng.forces(0)
         sim = None
         n_total = N
-
+    else:
+        # multi-site workloads: host-built phase space (fixtures of the reference's own tests), uploaded once
+        engine_mod = importlib.import_module("ls1-mardyn_amd.engine")
+        eng = engine_mod.DeviceEngine(local_rank)
+        if args.workload == "ethane":
+            ps0, _ = ethane_fixture(inp)
+            big = replicate_phase_space(inp, ps0, 10)
+            comps, rc_ms, L = big.components, ETHANE_RC, float(big.length[0])
+            ids_h, cid_h, r_h, v_h, q_h, D_h = big.ids, big.cid, big.r, big.v, big.q, big.D
+        else:
+            comps, L, ids_h, cid_h, r_h, q_h = mixed_box(inp, 171)
+            rc_ms = MIXED_RC
+            v_h, D_h = np.zeros_like(r_h), np.zeros_like(r_h)
+        eng.set_components(comps, rc_ms)
+        eng.set_option("force_kernel", args.kernel)
+        if args.skin > 0 and args.kernel != 1:
+            eng.set_verlet(args.skin)
+        eng.set_domain([L, L, L])
+        eng.upload(ids_h, cid_h, r_h, v_h, q_h, D_h)
+        N = len(ids_h)
+        del ids_h, cid_h, r_h, v_h, q_h, D_h
+        eng.rebin(); eng.halo(); eng.forces(0)
+        sim = None
+        n_total = N
     if args.no_fuse:
         (sim.engine if sim is not None else eng).set_option("fuse_integration", 0)
     if args.overlap >= 0:
@@ -297,10 +539,27 @@ def main():
     if args.precision != "dp":
         (sim.engine if sim is not None else eng).set_option("precision", {"spdp": 1, "spsp": 2}[args.precision])
 
+    step_dt = {"lj": DT, "ethane": ETHANE_DT, "mixed": 0.0}[args.workload]
+    mixed_state = {"since_build": 0}
+
     def run(k):
         if sim is not None:
             return sim.run(DT, k, fuse=not args.no_fuse, lists=None if os.environ.get("LS1_BENCH_DECOMP_LISTS", "1") != "0" else False)
-        return eng.run(DT, k)
+        if args.workload == "mixed":
+            # static configuration: a "step" is one complete force traversal with its per-step global values; the lists are
+            # rebuilt (re-bin + halo + build) every --rebuild-every traversals, the rhythm of the moving workloads
+            uw = None
+            for _ in range(k):
+                if eng.get_option("verlet_lists"):
+                    if mixed_state["since_build"] % args.rebuild_every == 0:
+                        eng.rebin(); eng.halo(); eng.verlet_build()
+                    mixed_state["since_build"] += 1
+                    uw = eng.forces_list(0, 0.0, want_macro=(_ == k - 1))
+                else:
+                    eng.rebin(); eng.halo()
+                    uw = eng.forces(0, want_macro=(_ == k - 1))
+            return {"upot": uw[0], "virial": uw[1]} if uw else None
+        return eng.run(step_dt, k)
 
     def sync():
         torch.cuda.synchronize()
@@ -309,6 +568,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if args.melt:
+        run(args.melt)
     run(args.warmup)
     e = sim.engine if sim is not None else eng
     e.timing_reset()
@@ -336,22 +597,29 @@ def main():
     integ_ms, _ = e.timing("integrate")
     rebin_ms, _ = e.timing("rebin")
     halo_ms, _ = e.timing("halo")
+    build_ms, build_n = e.timing("build")
     n_local = e.count()[0]
     # HBM traffic of the force kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction, WRITE_SIZE), taken
     # offline on this exact workload and committed under profiles/ (PMC collection cannot run inside the timed loop)
     fused_on = bool(e.get_option("fuse_integration")) and bool(e.get_option("can_fuse_integration"))
     n_fused = (args.steps - 1) if fused_on else 0  # the last step of a run is unfused (F and kinetic sums are needed)
-    alg_bytes_total = n_local * (FUSED_BYTES_PER_MOLECULE * n_fused + FORCE_BYTES_PER_MOLECULE * (args.steps - n_fused))
+    if args.workload == "lj":
+        alg_bytes_total = n_local * (FUSED_BYTES_PER_MOLECULE * n_fused + FORCE_BYTES_PER_MOLECULE * (args.steps - n_fused))
+        # whole step per GPU: plain = force 48 + integrator 120 + re-bin 124 = 292 B; fused = 96 + 124 = 220 B per molecule
+        step_bytes_total = n_local * ((FUSED_BYTES_PER_MOLECULE + 124.0) * n_fused + STEP_BYTES_PER_MOLECULE * (args.steps - n_fused))
+    else:
+        # multi-site force pass (48 B + 56 B for the orientation in and the torque out): read r 24 + q 32, write F 24 + M 24
+        alg_bytes_total = n_local * MS_FORCE_BYTES_PER_MOLECULE * args.steps
+        # + rigid-body integrator pass: read r v q D F M (152 B), write r v q D (104 B); static traversals (mixed) have none
+        step_bytes_total = n_local * (MS_FORCE_BYTES_PER_MOLECULE + (256.0 if args.workload == "ethane" else 0.0)) * args.steps
     alg_bytes_per_launch = alg_bytes_total / max(force_n, 1)
-    # whole step per GPU: plain = force 48 + integrator 120 + re-bin 124 = 292 B; fused = 96 + 124 = 220 B per molecule
-    step_bytes_total = n_local * ((FUSED_BYTES_PER_MOLECULE + 124.0) * n_fused + STEP_BYTES_PER_MOLECULE * (args.steps - n_fused))
     traffic = None
     pmc_extra = {}
     try:
         with open(os.path.join(ROOT, "profiles", PMC_SUMMARY)) as fh:
             js = json.load(fh)
         pm = js["force_kernel"]
-        if world == 1 and js.get("molecules") == n_local and e.get_option("cells_in_cutoff") == 1 and \
+        if args.workload == "lj" and world == 1 and js.get("molecules") == n_local and e.get_option("cells_in_cutoff") == 1 and \
                 bool(js.get("neighbour_lists")) == (e.get_option("verlet_builds") > 0) and \
                 e.get_option("force_kernel") in (0, 2) and e.get_option("lj_split") == 0 and \
                 abs(pm["algorithmic_bytes_per_launch"] / alg_bytes_per_launch - 1.0) < 0.03:
@@ -361,10 +629,14 @@ def main():
     except Exception:
         traffic = None
     traffic_source = f"profiles/{PMC_SUMMARY} (rocprofv3 --pmc passes of this workload, committed)" if traffic is not None else None
+    live_compute = None
     if rank == 0 and world == 1 and not args.no_live_pmc and not args.decomp:
         tail = ["--n-per-dim", str(n), "--skin", str(args.skin), "--kernel", str(args.kernel), "--cic", str(args.cic),
-                "--split", str(args.split)] + (["--no-fuse"] if args.no_fuse else [])
+                "--split", str(args.split), "--workload", args.workload, "--melt", str(min(args.melt, 40)),
+                "--rebuild-every", str(args.rebuild_every), "--precision", args.precision] + (["--no-fuse"] if args.no_fuse else []) + \
+               (["--nvt"] if args.nvt else [])
         live, what = live_pmc_traffic(tail)
+        live_compute, _what2 = live_pmc_compute(tail, force_ms / 1e3 / max(force_n, 1))
         if live is not None:
             # the child runs 6 timed steps (5 fused + 1 plain launch): same kernel, per-launch mean dominated by the fused form
             traffic = live
@@ -375,16 +647,33 @@ def main():
         avg_force_s = force_ms / 1e3 / max(force_n, 1)
         achieved = alg_bytes_total / (force_ms / 1e3) / 1e9
         value = n_total * args.steps / elapsed
+        if args.workload == "lj":
+            metric = BASELINE_METRIC if n == 368 else f"particle-updates/sec (whole node), N={n_total} LJ liquid Argon, rc=2.5\u03c3"
+            wl = (f"1CLJ Lennard-Jones liquid, N={n_total} = 2*{n}^3 (global box, split over {world} GPU(s)), "
+                  f"rho*={RHO}, rc={RC} sigma, dt={DT}, T*={TEMP}, NVE full time step (kick-drift, re-bin, halo, "
+                  f"forces, kick) with per-step U_pot / virial / sum mv^2, FP64")
+        elif args.workload == "ethane":
+            metric = f"particle-updates/sec (whole node), N={n_total} 2CLJ ethane, rc={ETHANE_RC} (BASELINE configs[3])"
+            wl = (f"2CLJ ethane (two LJ centres, rigid rotor): the reference's Ethan_equilibrated box (9 826 molecules, L=571.607759, "
+                  f"rc={ETHANE_RC}) replicated 10^3 = {n_total} molecules, dt={ETHANE_DT}, NVE full time step (rigid-body kick-drift, "
+                  f"re-bin + halo + list build on rebuild steps, site forces + torques, kick) with per-step U_pot / virial / "
+                  f"sum mv^2 / sum Iw^2, FP64")
+        else:
+            metric = f"molecule-force-evaluations/sec (whole node), N={n_total} five-component LJ+charge+dipole+quadrupole set, rc={MIXED_RC} (BASELINE configs[4])"
+            wl = (f"the five components of VectorizationMultiComponentMultiPotentials.inp (LJ + charge + dipole + quadrupole sites) "
+                  f"on a jittered 171^3 bcc lattice at the fixture's number density, component = id mod 5, N={n_total}, rc={MIXED_RC}; "
+                  f"a step = ONE complete force traversal (forces, torques, U_pot, virial) of the static configuration — two of the "
+                  f"five components are massless in the reference's fixture, the set cannot be integrated — with re-bin + halo + list "
+                  f"build every {args.rebuild_every} traversals, FP64")
         out = {
-            "metric": BASELINE_METRIC if n == 368 else f"particle-updates/sec (whole node), N={n_total} LJ liquid Argon, rc=2.5\u03c3",
+            "metric": metric,
             "value": value, "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": {"dp": "f64", "spdp": "f32 pair arithmetic, f64 sums and integration (SPDP mode, not the metric's precision)",
                                            "spsp": "f32 pair arithmetic and sums, f64 integration (SPSP mode, not the metric's precision)"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": f"1CLJ Lennard-Jones liquid, N={n_total} = 2*{n}^3 (global box, split over {world} GPU(s)), "
-                                   f"rho*={RHO}, rc={RC} sigma, dt={DT}, T*={TEMP}, NVE full time step (kick-drift, re-bin, halo, "
-                                   f"forces, kick) with per-step U_pot / virial / sum mv^2, FP64",
+            "config": {"workload": wl,
+                       "untimed_steps_before_the_timed_window": {"melt": args.melt, "warmup": args.warmup},
                        "molecules_per_gpu": n_local, "decomposition": getattr(sim, "grid_desc", "single GPU, periodic images local"),
                        "force_kernel": e.get_option("force_kernel"), "cells_in_cutoff": e.get_option("cells_in_cutoff"),
                        "neighbour_lists": ({"skin": args.skin, "list_builds": e.get_option("verlet_builds"),
@@ -403,10 +692,17 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "full_step_frac": step_bytes_total / elapsed / 1e9 / HBM_PEAK_GBS},
             "device_ms_per_step": {"force": force_ms / args.steps, "integrate": integ_ms / nprof,
-                                   "rebin": rebin_ms / nprof, "halo": halo_ms / nprof},
+                                   "rebin": rebin_ms / nprof, "halo": halo_ms / nprof, "list_build": build_ms / nprof,
+                                   "list_build_ms_per_build": (build_ms / build_n if build_n else None),
+                                   "list_builds_per_step": (e.get_option("verlet_builds") / max(e.get_option("verlet_steps"), 1)
+                                                            if e.get_option("verlet_lists") else 0.0),
+                                   "note": "force: mean over the timed steps; the other phases: mean over the profiling steps "
+                                           "after the timed window (rebuild steps included at their frequency)"},
             "last_step": {k: (float(v_) if not isinstance(v_, int) else v_) for k, v_ in last.items()} if isinstance(last, dict) else None,
         }
-        if pmc_extra:
+        if live_compute is not None:
+            out["roofline"]["compute"] = live_compute
+        elif pmc_extra:
             # the kernel is issue-bound, not HBM-bound: the FP64 vector rate actually sustained (PMC instruction counts
             # of this workload, profiles/, over the live launch time) next to the 78.6 TFLOP/s FP64 vector peak, and the
             # pipe utilisations of the same PMC passes
@@ -416,9 +712,14 @@ def main():
                 comp["fp64_frac"] = comp["fp64_tflops"] / 78.6
             comp.update({k: v for k, v in pmc_extra.items() if k != "fp64_flop_per_launch"})
             out["roofline"]["compute"] = comp
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+        if not args.no_cpu_baseline and world == 1 and args.workload != "mixed":
+            out["cpu_baseline"] = cpu_baseline(workload=args.workload)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        elif not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = {"value": None, "unit": "molecule-force-evaluations/s", "cores": 0, "kind": "reference",
+                                   "sample": "none: the reference driver cannot run this set (massless components); its force "
+                                             "traversal alone is timed by the reference's own VectorizationTuner, not by MarDyn's "
+                                             "Simulation speed line"}
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or args.decomp:

@@ -338,7 +338,7 @@ int ls1hip_soa_forces(ls1hip_ctx* ctx, const int cell_dims[3], const uint32_t* c
 /* ---- measurement ---------------------------------------------------------------------------------------------- */
 
 /* Device time (ms, HIP events on the context's compute stream) and launch count accumulated per kernel class
- * since the last reset: names[] in {"force","integrate","rebin","halo"}. */
+ * since the last reset: names[] in {"force","integrate","rebin","halo","build" (neighbour-list construction)}. */
 int ls1hip_timing(ls1hip_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);
 int ls1hip_timing_reset(ls1hip_ctx* ctx);
 /* Per-launch HIP-event timing: 0 = off, 1 = every phase, 2 = force passes only (each timed scope puts two event markers

@@ -106,6 +106,8 @@ static void free_mol(ls1hip_ctx* c) {
 	dfree(c->alt_x); dfree(c->alt_y); dfree(c->alt_z);
 	dfree(c->d_vl_words); dfree(c->d_vl_nw); dfree(c->d_vl_rec); dfree(c->d_vl_ii); dfree(c->d_vl_gi);
 	dfree(c->d_vl_top2); dfree(c->d_vl_acc);
+	dfree(c->d_msl_cnt); dfree(c->d_msl_off); dfree(c->d_msl_j); dfree(c->d_msl_il);
+	c->msl_groups_cap = c->msl_pairs_cap = 0;
 	dfree(c->seam_a_buf);
 	c->seam_a_cap = 0;
 	c->vl_words_cap = c->vl_tiles_cap = 0;
@@ -180,7 +182,7 @@ extern "C" int ls1hip_destroy(ls1hip_ctx* c) {
 	if (c->d_ingest) hipFree(c->d_ingest);
 	if (c->h_cnt) hipHostFree(c->h_cnt);
 	if (c->h_flag) hipHostFree((void*)c->h_flag);
-	timer_free(c->t_force); timer_free(c->t_integrate); timer_free(c->t_rebin); timer_free(c->t_halo);
+	timer_free(c->t_force); timer_free(c->t_integrate); timer_free(c->t_rebin); timer_free(c->t_halo); timer_free(c->t_build);
 	hipStreamDestroy(c->stream);
 	if (c->stream2) hipStreamDestroy(c->stream2);
 	if (c->ev_owned) hipEventDestroy(c->ev_owned);
@@ -436,6 +438,11 @@ extern "C" int ls1hip_set_domain(ls1hip_ctx* c, const double global_len[3], cons
 			}
 	c->nbr[13] = my_rank;
 	HIPCHK(c, hipSetDevice(c->device));
+	if (!c->d_shift27) {
+		int rs = dalloc(c, &c->d_shift27, 81);
+		if (rs) return rs;
+	}
+	HIPCHK(c, hipMemcpy(c->d_shift27, &c->shift[0][0], 81 * sizeof(double), hipMemcpyHostToDevice));
 	const size_t nc = (size_t)g.ncells;
 	if (nc > c->cells_alloc) {
 		free_cells(c);
@@ -695,7 +702,8 @@ extern "C" int ls1hip_upload_end(ls1hip_ctx* c) {
 	c->d_ingest = nullptr;
 	c->ingest_bytes = 0;
 	const size_t n = c->ingest_at;  // the announced total is an upper bound (it sized the device arrays)
-	if (c->vl_on && !c->vl_force && c->opt_cic == 1) {
+	if (c->vl_on && !c->vl_force && c->opt_cic == 1 && c->one_clj) {
+		// (multi-site sets keep their lists in any case: their pair streams need no staging, kernels_force_mslist.hip)
 		// Will the list kernels be able to stage a brick's region?  If the MEAN region already comes close to the capacity
 		// (large skin, dense system) the per-step kernels are the better loop — and they want the reference's r_c grid,
 		// not the r_c + skin one: the domain is set up again without the skin before anything is binned.
@@ -969,7 +977,13 @@ static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
 	// local rebuild criterion (kernels_force_verlet.hip, k_bound_local): complete fused traversals of a single periodic domain
 	const bool local_crit = fp.vl && fuse && which == 0 && !c->has_remote && c->opt_local_rebuild && c->d_vl_top2;
 	if (local_crit) P.vl_top2 = c->d_vl_top2;
-	if (fp.vl) {
+	if (fp.vl && !c->one_clj) {
+		if (which != 0) FAIL(c, LS1HIP_EINVAL, "multi-site neighbour lists serve complete traversals (which = 0)");
+		done = launch_force_ms_list(P, c->h_ct.has_rot != 0, c->d_msl_off, c->d_msl_j, c->d_msl_il, c->d_shift27, c->stream, &nblocks,
+									c->partials_cap);
+		if (!done) FAIL(c, LS1HIP_EINVAL, "multi-site neighbour-list force pass could not be launched");
+		family = LS1HIP_FK_NEIGHBOUR_LIST;
+	} else if (fp.vl) {
 		done = launch_force_verlet(P, c->stream, &nblocks, c->partials_cap, &c->brick_lists);
 		if (!done) FAIL(c, LS1HIP_EINVAL, "neighbour-list force pass could not be launched");
 		family = LS1HIP_FK_NEIGHBOUR_LIST;
@@ -1375,6 +1389,20 @@ extern "C" int ls1hip_set_verlet(ls1hip_ctx* c, int enabled, double skin) {
 // (a domain whose mean brick region would not fit the LDS staging area has had its lists switched off at upload time)
 static bool can_verlet(const ls1hip_ctx* c) { return c->vl_on && c->g.hw == 1 && !c->has_remote; }
 
+// host-visible word the step's last reduction / the drift pass publishes {sequence, rebuild needed} to
+static int ensure_rebuild_flag(ls1hip_ctx* c) {
+	if (!c->h_flag) {
+		void* h = nullptr;
+		HIPCHK(c, hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent));
+		c->h_flag = (volatile uint32_t*)h;
+		*c->h_flag = 0;
+		void* d = nullptr;
+		HIPCHK(c, hipHostGetDevicePointer(&d, h, 0));
+		c->d_flag = (uint32_t*)d;
+	}
+	return LS1HIP_OK;
+}
+
 static int ensure_verlet_buffers(ls1hip_ctx* c) {
 	long nbricks;
 	size_t wpb, tpb;
@@ -1398,23 +1426,14 @@ static int ensure_verlet_buffers(ls1hip_ctx* c) {
 		c->vl_words_cap = words;
 		c->vl_tiles_cap = tiles;
 	}
-	if (!c->h_flag) {
-		void* h = nullptr;
-		HIPCHK(c, hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent));
-		c->h_flag = (volatile uint32_t*)h;
-		*c->h_flag = 0;
-		void* d = nullptr;
-		HIPCHK(c, hipHostGetDevicePointer(&d, h, 0));
-		c->d_flag = (uint32_t*)d;
-	}
-	return LS1HIP_OK;
+	return ensure_rebuild_flag(c);
 }
 
 // lists of all bricks from the freshly binned molecules + halo copies in mol[cur]
 static int verlet_build(ls1hip_ctx* c) {
 	int rc = ensure_verlet_buffers(c);
 	if (rc) return rc;
-	TimedScope ts(c, c->t_rebin);  // list construction belongs to the re-binning work of a rebuild step
+	TimedScope ts(c, c->t_build);  // list construction: its own timer ("build"), next to the re-binning of a rebuild step
 	ForceParams P;
 	fill_force_params(c, P, 0);
 	P.vl_mode = 1;
@@ -1478,17 +1497,61 @@ static int verlet_poll_rebuild(ls1hip_ctx* c, bool* need) {
 
 // ---- list mode, piecewise (multi-rank loops drive these; ls1hip_run is the single-rank loop) -------------------------------
 // lists serve the single-centre LJ fast path on a one-cell-per-cutoff grid; FUSED list passes additionally need can_fuse()
-static bool can_list(const ls1hip_ctx* c) {
+static bool can_list_lj(const ls1hip_ctx* c) {
 	return c->vl_on && c->one_clj && c->opt_force_kernel != LS1HIP_FK_GENERIC && !c->opt_vi && !c->opt_count_pairs && c->g.hw == 1;
+}
+// multi-site component sets: per-wave pair streams (kernels_force_mslist.hip); single-rank domains, complete traversals
+static bool can_list_ms(const ls1hip_ctx* c) {
+	return c->vl_on && c->have_comp && !c->one_clj && c->opt_force_kernel != LS1HIP_FK_GENERIC && !c->opt_vi && !c->opt_count_pairs &&
+		   c->g.hw == 1 && !c->has_remote && c->n_real + c->cap_halo < (size_t)0x07ffffff;
+}
+static bool can_list(const ls1hip_ctx* c) { return can_list_lj(c) || can_list_ms(c); }
+
+// pair streams of all groups from the freshly binned molecules + halo copies in mol[cur]
+static int msl_build(ls1hip_ctx* c) {
+	int rc = ensure_rebuild_flag(c);
+	if (rc) return rc;
+	TimedScope ts(c, c->t_build);
+	const uint32_t ng = msl_groups((uint32_t)c->n_real);
+	if ((size_t)ng + 1 > c->msl_groups_cap) {
+		dfree(c->d_msl_cnt);
+		dfree(c->d_msl_off);
+		c->msl_groups_cap = 0;
+		if ((rc = dalloc(c, &c->d_msl_cnt, (size_t)ng + 1)) || (rc = dalloc(c, &c->d_msl_off, (size_t)ng + 2))) return rc;
+		c->msl_groups_cap = (size_t)ng + 1;
+	}
+	ForceParams P;
+	fill_force_params(c, P, 0);
+	launch_msl_count(P, c->d_msl_cnt, c->d_msl_off, c->stream);
+	HIPCHK(c, hipGetLastError());
+	// one host round trip per list build: the pair count sizes the stream
+	unsigned long long total = 0;
+	HIPCHK(c, hipMemcpyAsync(&total, &c->d_cnt->msl_total, sizeof(total), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	REQUIRE(c, total < 0xffffffc0ull, "multi-site neighbour lists: %llu pairs exceed the 32-bit pair index", total);
+	if (total > c->msl_pairs_cap) {
+		dfree(c->d_msl_j);
+		dfree(c->d_msl_il);
+		c->msl_pairs_cap = 0;
+		const size_t want = (size_t)(total + total / 8 + 4096);
+		if ((rc = dalloc(c, &c->d_msl_j, want)) || (rc = dalloc(c, &c->d_msl_il, want))) return rc;
+		c->msl_pairs_cap = want;
+	}
+	c->msl_pairs = total;
+	launch_msl_fill(P, c->d_msl_off, c->d_halo_src, c->d_halo_dir, c->d_msl_j, c->d_msl_il, c->h_ct.ncomp, c->stream);
+	HIPCHK(c, hipGetLastError());
+	c->vl_builds++;
+	c->vl_all_regular = false;
+	return LS1HIP_OK;
 }
 
 extern "C" int ls1hip_verlet_build(ls1hip_ctx* c) {
 	if (!c) return LS1HIP_EINVAL;
-	REQUIRE(c, can_list(c), "neighbour lists need ls1hip_set_verlet, the single-centre LJ fast path and one cell per cutoff");
+	REQUIRE(c, can_list(c), "neighbour lists need ls1hip_set_verlet and one cell per cutoff (single-centre LJ fast path, or a multi-site set on a single-rank domain)");
 	REQUIRE(c, c->binned && c->halo_valid, "neighbour lists are built from binned molecules and a populated halo");
 	REQUIRE(c, !c->inner_in_flight && !c->fused_split, "a split force pass is in flight");
 	HIPCHK(c, hipSetDevice(c->device));
-	int rc = verlet_build(c);
+	int rc = can_list_lj(c) ? verlet_build(c) : msl_build(c);
 	if (rc) return rc;
 	// the export counts / import total of this halo exchange are what every refresh until the next build repeats
 	if ((rc = sync_counters(c))) return rc;
@@ -1621,6 +1684,8 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 	const bool fuse = c->opt_fuse && can_fuse(c);
 	// neighbour-list loop (fused or not: NVT and unfused NVE steps advance the displacement bound in their kick + drift pass)
 	const bool verlet = can_verlet(c) && can_list(c);
+	// the single-centre list pass does the post-force kick (+ sum m v^2) itself; the multi-site one leaves it to the integrator passes
+	const bool list_kick = verlet && c->one_clj;
 	bool advanced = false;  // the previous force pass already did kick + kick + drift
 	// step log: one row {U_pot, virial, sum m v^2, sum I w^2, N, rotDOF} per step, written by the reductions on the device
 	if (!c->d_steplog) {
@@ -1646,9 +1711,9 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 			// passes: kick (+ sums, betas on the device) -> scale -> kick+drift   (Simulation.cpp:1099-1131)
 			// (the scaling itself is folded into the kick + drift pass, with the betas the kick's reduction left on the device)
 			// In list mode the force pass of step s-1 has done the post-force kick and the kinetic sum (betas on the device).
-			if (!verlet && (rc = ls1hip_kick(c, 0.5 * dt, nullptr, nullptr, nullptr, nullptr))) return rc;
+			if (!list_kick && (rc = ls1hip_kick(c, 0.5 * dt, nullptr, nullptr, nullptr, nullptr))) return rc;
 			if ((rc = kick_drift_impl(c, dt, 2, 1., 1.))) return rc;
-		} else if (verlet) {
+		} else if (list_kick) {
 			if ((rc = ls1hip_kick_drift(c, dt))) return rc;  // (post-force kick already done by the list force pass)
 		} else {
 			// post-force kick of step s-1 fused with the pre-force kick+drift of step s (same F, one pass)
@@ -1660,7 +1725,8 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 			// the device by whichever pass drifts them) exceeds skin / 2; then re-bin, regenerate the halo, rebuild the lists
 			if ((rc = ls1hip_update(c, nullptr))) return rc;
 			// unfused steps (the last one; every step of an NVT run): the pass still does the post-force kick + sum m v^2
-			rc = advanced ? ls1hip_forces_list(c, 0, dt, nullptr, nullptr) : forces_list_impl(c, 0, dt, true, nullptr, nullptr);
+			rc = advanced ? ls1hip_forces_list(c, 0, dt, nullptr, nullptr)
+						  : forces_list_impl(c, 0, list_kick ? dt : 0., list_kick, nullptr, nullptr);
 		} else if (c->opt_overlap_halo == 2) {
 			if ((rc = ls1hip_rebin(c))) return rc;
 			// halo first, then the inner and the boundary cells as two passes of the same stream
@@ -1683,7 +1749,7 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 		if (rc) return rc;
 		if (s + 1 == nsteps) {
 			c->log_row_kin = c->log_row;
-			if (!verlet && (rc = ls1hip_kick(c, 0.5 * dt, nullptr, nullptr, nullptr, nullptr))) return rc;
+			if (!list_kick && (rc = ls1hip_kick(c, 0.5 * dt, nullptr, nullptr, nullptr, nullptr))) return rc;
 			if (c->thermostat_on) {
 				TimedScope ts(c, c->t_integrate);
 				launch_scale(integ_args(c, 0.), 1., 1., true, c->stream);
@@ -2000,6 +2066,7 @@ static Timer* timer_by_name(ls1hip_ctx* c, const char* name) {
 	if (n == "force") return &c->t_force;
 	if (n == "integrate") return &c->t_integrate;
 	if (n == "rebin") return &c->t_rebin;
+	if (n == "build") return &c->t_build;
 	if (n == "halo") return &c->t_halo;
 	return nullptr;
 }
@@ -2017,7 +2084,7 @@ extern "C" int ls1hip_timing(ls1hip_ctx* c, const char* name, double* total_ms, 
 
 extern "C" int ls1hip_timing_reset(ls1hip_ctx* c) {
 	if (!c) return LS1HIP_EINVAL;
-	for (Timer* t : {&c->t_force, &c->t_integrate, &c->t_rebin, &c->t_halo}) {
+	for (Timer* t : {&c->t_force, &c->t_integrate, &c->t_rebin, &c->t_halo, &c->t_build}) {
 		timer_collect(*t);
 		t->total_ms = 0;
 		t->launches = 0;

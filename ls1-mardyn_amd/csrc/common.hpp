@@ -54,6 +54,7 @@ struct DevCounters {
 	uint32_t vl_irregular;      // list build: bricks without a complete set of stored lists (unstaged, overflow)
 	uint32_t vl_local_excess;   // local rebuild criterion: some brick neighbourhood's pair-displacement bound exceeds skin / 2
 	unsigned long long dist_checks, pairs_in_range;
+	unsigned long long msl_total;  // multi-site pair lists: pairs (incl. block padding) of the last build
 	double vmax2;          // list-reuse mode: max |v|^2 of the drift velocities of the current step
 	double vl_bound;       // upper bound of the displacement of any molecule since the neighbour lists were built
 	double vl_base;        // local criterion: the part of that bound added by UNFUSED drifts (they only know the global v_max)
@@ -183,7 +184,7 @@ struct ls1hip_ctx {
 	double thermostat_T = 0.;
 	// timing
 	int timing_on = 0;  // 0 off, 1 all phases, 2 force passes only
-	ls1::Timer t_force, t_integrate, t_rebin, t_halo;
+	ls1::Timer t_force, t_integrate, t_rebin, t_halo, t_build;  // "build" = neighbour-list construction
 	std::vector<void*> allocs;
 	// neighbour-list reuse (ls1hip_set_verlet; kernels_force_verlet.hip)
 	bool vl_on = false, vl_force = false;
@@ -216,6 +217,12 @@ struct ls1hip_ctx {
 	uint32_t* d_flag = nullptr;
 	uint32_t vl_seq = 0;
 	unsigned long vl_builds = 0, vl_steps = 0;
+	// multi-site neighbour lists (kernels_force_mslist.hip): per group of 128 owned molecules one block of molecule pairs
+	uint32_t *d_msl_cnt = nullptr, *d_msl_off = nullptr, *d_msl_j = nullptr;
+	uint8_t* d_msl_il = nullptr;
+	size_t msl_groups_cap = 0, msl_pairs_cap = 0;
+	unsigned long long msl_pairs = 0;  // pairs of the current lists (incl. padding)
+	double* d_shift27 = nullptr;        // device copy of shift[27][3]
 	// per-step globals of ls1hip_run (ls1hip_run_log): rows of 6 doubles, written by the reduction kernels
 	double* d_steplog = nullptr;
 	double *log_row = nullptr, *log_row_kin = nullptr;  // rows the next force / kinetic reduction refreshes (null outside ls1hip_run)
@@ -340,6 +347,14 @@ bool launch_force_ms(const ForceParams& p, bool with_vi, bool has_rot, bool one_
 // site kernel (kernels_force_sites.hip): LDS-resident tables, cached own sites, LPM lanes per molecule, launch-time brick shape
 bool launch_force_sites(const ForceParams& p, const CompTable& hct, bool with_vi, hipStream_t s, uint32_t* nblocks,
 						size_t partials_cap, double mean_per_cell, double mean_neighbours, BrickLists* bl);
+// multi-site neighbour lists (kernels_force_mslist.hip): count + offsets, fill, force pass over the pair stream
+int msl_group_size();
+uint32_t msl_groups(uint32_t n_real);
+void launch_msl_count(const ForceParams& p, uint32_t* grp_cnt, uint32_t* off, hipStream_t s);
+void launch_msl_fill(const ForceParams& p, const uint32_t* off, const uint32_t* hsrc, const uint8_t* hdir, uint32_t* out_j,
+					 uint8_t* out_il, int ncomp, hipStream_t s);
+bool launch_force_ms_list(const ForceParams& p, bool has_rot, const uint32_t* off, const uint32_t* pj, const uint8_t* pil,
+						  const double* shift27, hipStream_t s, uint32_t* nblocks, size_t partials_cap);
 // kin_in_slot1: the partials' slot 1 carries sum m v^2 of a fused force + integration pass (goes to cnt->kin[0], not to
 // the macroscopic sums); log (may be null): the step-log row {U_pot, virial, sum m v^2, sum I w^2, N, rotDOF} to refresh
 struct ReduceMode {

@@ -234,7 +234,12 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 		VAcc acc = {0., 0., 0., 0., 0., 0u};
 		// the epilogue's velocity loads are issued before the pair loop (their latency is hidden behind it)
 		double vx0 = 0., vy0 = 0., vz0 = 0.;
-		if (active && P.fuse) {
+#ifdef LS1_NOEPI_MOCK
+		const bool epi = P.which != 0;  // run-time false in the bench's single-pass traversal: no velocity loads, no stores
+#else
+		const bool epi = true;
+#endif
+		if (active && P.fuse && epi) {
 			vx0 = P.vx[gi];
 			vy0 = P.vy[gi];
 			vz0 = P.vz[gi];
@@ -249,7 +254,11 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 			// row register is reloaded right after its content is consumed — ONE loop-carried value per row: with a rotating
 			// window (w0 <- w1 <- w2 <- w3) the compiler sank every load to its use and waited vmcnt(0) on it, i.e. a dependent
 			// HBM round trip per four pairs; a load inside a branch has the same effect (seen in the ISA).
-#if defined(LS1_N3_MOCK) || defined(LS1_SHORT_MOCK)
+#if defined(LS1_PASS2_MOCK)
+			const uint32_t last = pass != 0 ? 3u : nw - 1u;
+#elif defined(LS1_NOLOOP_MOCK)
+			const uint32_t last = 3u;
+#elif defined(LS1_N3_MOCK) || defined(LS1_SHORT_MOCK)
 			const uint32_t last = max(4u, (nw * 2u + 2u) / 3u) - 1u;
 #else
 			const uint32_t last = nw - 1u;  // nw >= 4: rows are dummy-padded by the build
@@ -289,6 +298,21 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 #ifdef LS1_SHORT_MOCK
 			nw = max(4u, (nw * 2u + 2u) / 3u);  // the shorter lists alone (no accumulator traffic)
 #endif
+#ifdef LS1_NOLOOP_MOCK
+			nw = 0;  // everything but the pair loop: staging, list head, epilogue, reductions
+#endif
+#ifdef LS1_PASS2_MOCK
+			if (pass != 0) nw = 4;  // what would a (nearly) free second pass be worth?  (a handful of molecules beyond the 512th)
+#endif
+#ifdef LS1_NOLIST_MOCK
+			for (uint32_t k = 0; k < nw; k += 4) {  // the pair loop without its list traffic (rows 0-3 over and over)
+				four_pairs(r0);
+				if (k + 1 < nw) four_pairs(r1);
+				if (k + 2 < nw) four_pairs(r2);
+				if (k + 3 < nw) four_pairs(r3);
+				r0 += (uint64_t)(k & 0u);  // keep the loop-carried form
+			}
+#else
 			for (uint32_t k = 0; k < nw; k += 4) {
 				// rows past the end are clamped to the last row and evaluated as what they are after the clamp: skipped
 				four_pairs(r0);
@@ -300,6 +324,7 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 				if (k + 3 < nw) four_pairs(r3);
 				r3 = load_row(wp + (size_t)min(k + 7u, last) * 64);
 			}
+#endif
 		} else if (active && staged) {
 			// no stored list for this tile (list overflow, or more owned molecules than the list capacity covers)
 			const double xi = sx[ii], yi = sy[ii], zi = sz[ii];
@@ -321,9 +346,16 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 				}
 			}
 		}
-		if (active) {
+		if (active && epi) {
 			v_pair_scale(acc, eps24);
+#if defined(LS1_N3_MOCK) || defined(LS1_SHORT_MOCK) || defined(LS1_NOLOOP_MOCK) || defined(LS1_NOLIST_MOCK) || defined(LS1_PASS2_MOCK)
+			// timing mocks evaluate an incomplete pair set: their (finite, wrong) forces are scaled by a run-time zero so that the
+			// molecules keep moving ballistically instead of blowing up
+			const double mz = (double)P.which;  // 0 in the single-pass traversal the bench runs
+			const double fx = acc.fx * mz, fy = acc.fy * mz, fz = acc.fz * mz;
+#else
 			const double fx = acc.fx, fy = acc.fy, fz = acc.fz;
+#endif
 			if (!P.fuse) {
 				P.Fx[gi] = fx;
 				P.Fy[gi] = fy;
@@ -779,6 +811,15 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet(ForceParams P, int n
 	}
 	ListHead head;
 	Totals tot = {0., 0., 0., 0., 0.};
+#ifdef LS1_ONE_WG_MOCK
+	__shared__ double ballast[4096];  // + 32 KB: one workgroup per CU (does the second workgroup of a CU hide anything?)
+	if (P.which == 7) ballast[tid] = 1.;
+#endif
+#ifdef LS1_STAGGER_MOCK
+	// first generation only: the second workgroup of every CU starts half a workgroup life late (anti-phase instead of lockstep)
+	if (blockIdx.x >= 256u && blockIdx.x < 512u)
+		for (int i = 0; i < LS1_STAGGER_MOCK; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
 	uint32_t* const rec = P.vl_rec + (size_t)bs.id * VREC;
 	// own LDS slot / global index of the first pass, issued together with the list head and the flags (reads of valid memory
 	// whatever the flags say): nothing the pair loop needs is requested after the staging barrier
@@ -794,6 +835,9 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet(ForceParams P, int n
 		head = load_list_head(P, bs.id, wv, lane);  // list head and own indices: independent of everything staged below
 		ii0 = f_ii[tid];
 		gi0 = f_gi[tid];
+#ifdef LS1_NOSTAGE_MOCK
+		if (P.which != 0)  // run-time false: the staging is skipped
+#endif
 		stage_positions(P, R, sx, sy, sz);
 		if (tid == 0) {
 			cstart[VNRC] = rec[VNRC];

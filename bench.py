@@ -510,7 +510,7 @@ def main():
         eng = engine_mod.DeviceEngine(local_rank)
         if args.workload == "ethane":
             ps0, _ = ethane_fixture(inp)
-            big = replicate_phase_space(inp, ps0, 10)
+            big = replicate_phase_space(inp, ps0, int(os.environ.get("LS1_BENCH_ETHANE_K", "10")))  # (K: diagnostics only)
             comps, rc_ms, L = big.components, ETHANE_RC, float(big.length[0])
             ids_h, cid_h, r_h, v_h, q_h, D_h = big.ids, big.cid, big.r, big.v, big.q, big.D
         else:

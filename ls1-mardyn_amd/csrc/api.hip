@@ -106,8 +106,8 @@ static void free_mol(ls1hip_ctx* c) {
 	dfree(c->alt_x); dfree(c->alt_y); dfree(c->alt_z);
 	dfree(c->d_vl_words); dfree(c->d_vl_nw); dfree(c->d_vl_rec); dfree(c->d_vl_ii); dfree(c->d_vl_gi);
 	dfree(c->d_vl_top2); dfree(c->d_vl_acc);
-	dfree(c->d_msl_cnt); dfree(c->d_msl_off); dfree(c->d_msl_j); dfree(c->d_msl_il);
-	c->msl_groups_cap = c->msl_pairs_cap = 0;
+	dfree(c->d_msl_cnt); dfree(c->d_msl_off); dfree(c->d_msl_j); dfree(c->d_msl_il); dfree(c->d_msl_scratch); dfree(c->d_msl_mcnt); dfree(c->d_msl_pk);
+	c->msl_groups_cap = c->msl_pairs_cap = c->msl_stride = 0;
 	dfree(c->seam_a_buf);
 	c->seam_a_cap = 0;
 	c->vl_words_cap = c->vl_tiles_cap = 0;
@@ -979,8 +979,8 @@ static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
 	if (local_crit) P.vl_top2 = c->d_vl_top2;
 	if (fp.vl && !c->one_clj) {
 		if (which != 0) FAIL(c, LS1HIP_EINVAL, "multi-site neighbour lists serve complete traversals (which = 0)");
-		done = launch_force_ms_list(P, c->h_ct.has_rot != 0, c->d_msl_off, c->d_msl_j, c->d_msl_il, c->d_shift27, c->stream, &nblocks,
-									c->partials_cap);
+		done = launch_force_ms_list(P, c->h_ct.has_rot != 0, c->h_ct.ncomp, c->d_msl_off, c->d_msl_j, c->d_msl_il, c->d_shift27, c->d_msl_pk,
+									c->stream, &nblocks, c->partials_cap);
 		if (!done) FAIL(c, LS1HIP_EINVAL, "multi-site neighbour-list force pass could not be launched");
 		family = LS1HIP_FK_NEIGHBOUR_LIST;
 	} else if (fp.vl) {
@@ -1520,9 +1520,20 @@ static int msl_build(ls1hip_ctx* c) {
 		if ((rc = dalloc(c, &c->d_msl_cnt, (size_t)ng + 1)) || (rc = dalloc(c, &c->d_msl_off, (size_t)ng + 2))) return rc;
 		c->msl_groups_cap = (size_t)ng + 1;
 	}
+	if (c->n_real > c->msl_stride) {
+		dfree(c->d_msl_scratch);
+		dfree(c->d_msl_mcnt);
+		dfree(c->d_msl_pk);
+		c->msl_stride = 0;
+		const size_t stride = (c->cap_real + 63) & ~(size_t)63;
+		if ((rc = dalloc(c, &c->d_msl_scratch, stride * (size_t)msl_capture_cap())) || (rc = dalloc(c, &c->d_msl_mcnt, stride)) ||
+			(rc = dalloc(c, &c->d_msl_pk, stride * 8)))
+			return rc;
+		c->msl_stride = stride;
+	}
 	ForceParams P;
 	fill_force_params(c, P, 0);
-	launch_msl_count(P, c->d_msl_cnt, c->d_msl_off, c->stream);
+	launch_msl_count(P, c->d_msl_cnt, c->d_msl_off, c->d_msl_scratch, c->d_msl_mcnt, (uint32_t)c->msl_stride, c->stream);
 	HIPCHK(c, hipGetLastError());
 	// one host round trip per list build: the pair count sizes the stream
 	unsigned long long total = 0;
@@ -1538,7 +1549,8 @@ static int msl_build(ls1hip_ctx* c) {
 		c->msl_pairs_cap = want;
 	}
 	c->msl_pairs = total;
-	launch_msl_fill(P, c->d_msl_off, c->d_halo_src, c->d_halo_dir, c->d_msl_j, c->d_msl_il, c->h_ct.ncomp, c->stream);
+	launch_msl_fill(P, c->d_msl_off, c->d_halo_src, c->d_halo_dir, c->d_msl_j, c->d_msl_il, c->h_ct.ncomp, c->d_msl_scratch, c->d_msl_mcnt,
+					(uint32_t)c->msl_stride, c->stream);
 	HIPCHK(c, hipGetLastError());
 	c->vl_builds++;
 	c->vl_all_regular = false;

@@ -220,6 +220,10 @@ struct ls1hip_ctx {
 	// multi-site neighbour lists (kernels_force_mslist.hip): per group of 128 owned molecules one block of molecule pairs
 	uint32_t *d_msl_cnt = nullptr, *d_msl_off = nullptr, *d_msl_j = nullptr;
 	uint8_t* d_msl_il = nullptr;
+	uint32_t* d_msl_scratch = nullptr;  // [msl_capture_cap()][msl_stride]: hits captured by the count kernel
+	uint16_t* d_msl_mcnt = nullptr;     // [msl_stride]: hits per molecule
+	double* d_msl_pk = nullptr;         // [msl_stride][8]: packed per-step state of the owned molecules (k_msl_pack)
+	size_t msl_stride = 0;
 	size_t msl_groups_cap = 0, msl_pairs_cap = 0;
 	unsigned long long msl_pairs = 0;  // pairs of the current lists (incl. padding)
 	double* d_shift27 = nullptr;        // device copy of shift[27][3]
@@ -350,11 +354,13 @@ bool launch_force_sites(const ForceParams& p, const CompTable& hct, bool with_vi
 // multi-site neighbour lists (kernels_force_mslist.hip): count + offsets, fill, force pass over the pair stream
 int msl_group_size();
 uint32_t msl_groups(uint32_t n_real);
-void launch_msl_count(const ForceParams& p, uint32_t* grp_cnt, uint32_t* off, hipStream_t s);
+int msl_capture_cap();  // hits per molecule the count kernel keeps for the fill kernel (scratch[k][stride])
+void launch_msl_count(const ForceParams& p, uint32_t* grp_cnt, uint32_t* off, uint32_t* scratch, uint16_t* mcnt, uint32_t stride,
+					  hipStream_t s);
 void launch_msl_fill(const ForceParams& p, const uint32_t* off, const uint32_t* hsrc, const uint8_t* hdir, uint32_t* out_j,
-					 uint8_t* out_il, int ncomp, hipStream_t s);
-bool launch_force_ms_list(const ForceParams& p, bool has_rot, const uint32_t* off, const uint32_t* pj, const uint8_t* pil,
-						  const double* shift27, hipStream_t s, uint32_t* nblocks, size_t partials_cap);
+					 uint8_t* out_il, int ncomp, const uint32_t* scratch, const uint16_t* mcnt, uint32_t stride, hipStream_t s);
+bool launch_force_ms_list(const ForceParams& p, bool has_rot, int ncomp, const uint32_t* off, const uint32_t* pj, const uint8_t* pil,
+						  const double* shift27, double* pk, hipStream_t s, uint32_t* nblocks, size_t partials_cap);
 // kin_in_slot1: the partials' slot 1 carries sum m v^2 of a fused force + integration pass (goes to cnt->kin[0], not to
 // the macroscopic sums); log (may be null): the step-log row {U_pot, virial, sum m v^2, sum I w^2, N, rotDOF} to refresh
 struct ReduceMode {

@@ -26,6 +26,28 @@
 // Reference semantics: pair set and masks as kernels_force.hip (VectorizedCellProcessor.cpp:2734-2821, centre-of-mass cutoff,
 // strict <, r^2 != 0), bodies = mol_pair (molpair.hpp: potforce.h:282-503), macroscopic sums with weight 1/2 per ordered pair.
 // Precedent for list reuse in the reference: AutoPasContainer.cpp:281-346.
+// pair arithmetic of THIS translation unit: FMA contraction on, reciprocals / square roots by the hardware estimate + two
+// Newton steps (see pairphys.hpp); results stay within 1e-13 of the IEEE bodies of the other kernels
+#pragma clang fp contract(fast)
+#include <hip/hip_runtime.h>
+namespace ls1 {
+__device__ __forceinline__ double msl_rcp(double d) {
+	double x = __builtin_amdgcn_rcp(d);
+	double e = fma(-d, x, 1.0);
+	x = fma(x, e, x);
+	e = fma(-d, x, 1.0);
+	return fma(x, e, x);
+}
+__device__ __forceinline__ double msl_rsq(double d) {
+	double y = __builtin_amdgcn_rsq(d);
+	double e = fma(-d * y, y, 1.0);
+	y = fma(0.5 * y, e, y);
+	e = fma(-d * y, y, 1.0);
+	return fma(0.5 * y, e, y);
+}
+}  // namespace ls1
+#define LS1_PAIR_RCP(x) ::ls1::msl_rcp(x)
+#define LS1_PAIR_SQRT(x) ((x) * ::ls1::msl_rsq(x))
 #include "common.hpp"
 
 namespace ls1 {
@@ -45,35 +67,67 @@ __device__ __forceinline__ double msl_wave_sum_d(double v) {
 	return v;
 }
 
-// Visit every molecule j != p of the 27 cells around p's cell with centre distance < rcl (list cutoff).
+// Visit every molecule j != p of the 27 cells around p's cell with centre distance < rcl (list cutoff).  The three cells of an
+// x row are neighbours in the cell table; where their molecule ranges are contiguous in memory (all owned or all halo cells:
+// the usual case) the row is ONE run of candidates, and the candidates are fetched four at a time (independent loads) — the
+// walk is a chain of dependent loads otherwise (cell table -> positions), 27 times per molecule.
 template <class F>
 __device__ __forceinline__ void msl_walk(const ForceParams& P, uint32_t p, double rcl2, F&& hit) {
 	int cx, cy, cz;
 	cell_coords(P.g, (int)P.ckey[p], cx, cy, cz);
 	const double xi = P.x[p], yi = P.y[p], zi = P.z[p];
+	auto run = [&](uint32_t jb, uint32_t je) {
+		uint32_t j = jb;
+		for (; j + 4u <= je; j += 4u) {
+			double ex[4], ey[4], ez[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				ex[u] = xi - P.x[j + u];
+				ey[u] = yi - P.y[j + u];
+				ez[u] = zi - P.z[j + u];
+			}
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const double dd = ex[u] * ex[u] + ey[u] * ey[u] + ez[u] * ez[u];
+				if (dd < rcl2 && j + u != p) hit(j + u);
+			}
+		}
+		for (; j < je; ++j) {
+			const double ex = xi - P.x[j], ey = yi - P.y[j], ez = zi - P.z[j];
+			const double dd = ex * ex + ey * ey + ez * ez;
+			if (dd < rcl2 && j != p) hit(j);
+		}
+	};
 	for (int dz = -1; dz <= 1; ++dz)
 		for (int dy = -1; dy <= 1; ++dy) {
-			// the three cells of an x row are consecutive in the cell table: one run of molecules when they are all owned or
-			// all halo cells, else walked cell by cell (owned and halo molecules live in different index segments)
-			for (int dx = -1; dx <= 1; ++dx) {
-				const int c2 = cell_index(P.g, cx + dx, cy + dy, cz + dz);
-				const uint32_t jb = P.cell_begin[c2], je = P.cell_end[c2];
-				for (uint32_t j = jb; j < je; ++j) {
-					const double ex = xi - P.x[j], ey = yi - P.y[j], ez = zi - P.z[j];
-					const double dd = ex * ex + ey * ey + ez * ez;
-					if (dd < rcl2 && j != p) hit(j);
-				}
+			const int c0 = cell_index(P.g, cx - 1, cy + dy, cz + dz);
+			const uint32_t b0 = P.cell_begin[c0], e0 = P.cell_end[c0], b1 = P.cell_begin[c0 + 1], e1 = P.cell_end[c0 + 1],
+						   b2 = P.cell_begin[c0 + 2], e2 = P.cell_end[c0 + 2];
+			if (e0 == b1 && e1 == b2) {
+				run(b0, e2);
+			} else {
+				run(b0, e0);
+				run(b1, e1);
+				run(b2, e2);
 			}
 		}
 }
 
-// ---- BUILD 1: pairs per group -----------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(MSG) k_msl_count(ForceParams P, uint32_t* grp_cnt) {
+// ---- BUILD 1: pairs per group; the hits of every molecule are kept (first MSL_CAP of them) for the fill kernel ------------------
+constexpr int MSL_CAP = 32;  // captured hits per molecule: scratch[k][p], k < MSL_CAP (coalesced over p); more: the fill kernel walks again
+__global__ void __launch_bounds__(MSG) k_msl_count(ForceParams P, uint32_t* grp_cnt, uint32_t* __restrict__ scratch,
+												   uint16_t* __restrict__ mcnt, uint32_t stride) {
 	__shared__ uint32_t wsum[MSG / 64];
 	const uint32_t n_real = P.n_fixed ? P.n_fixed : P.cnt->n_real;
 	const uint32_t p = blockIdx.x * MSG + threadIdx.x;
 	uint32_t cnt = 0;
-	if (p < n_real) msl_walk(P, p, P.vl_rc2, [&](uint32_t) { ++cnt; });
+	if (p < n_real) {
+		msl_walk(P, p, P.vl_rc2, [&](uint32_t j) {
+			if (cnt < (uint32_t)MSL_CAP) scratch[(size_t)cnt * stride + p] = j;
+			++cnt;
+		});
+		mcnt[p] = (uint16_t)min(cnt, 0xffffu);
+	}
 	cnt = msl_wave_sum(cnt);
 	if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
 	__syncthreads();
@@ -112,11 +166,23 @@ __global__ void __launch_bounds__(1024) k_msl_scan(const uint32_t* grp_cnt, uint
 }
 
 // ---- BUILD 3: fill the blocks, sorted by (component pair, local molecule, candidate order) -------------------------------------
-// Deterministic counting sort without atomics: walk 1 tallies per lane and component pair, a type-major scan turns the tallies
-// into private write cursors, walk 2 writes.
+// Deterministic counting sort without atomics: pass 1 tallies per lane and component pair, a type-major scan turns the tallies
+// into private write cursors, pass 2 writes.  Both passes read the hits the count kernel captured (no second / third walk of the
+// cell neighbourhood); a molecule with more hits than the capture holds walks again.
+template <class F>
+__device__ __forceinline__ void msl_hits(const ForceParams& P, uint32_t p, uint32_t cnt, const uint32_t* __restrict__ scratch,
+										 uint32_t stride, F&& hit) {
+	if (cnt <= (uint32_t)MSL_CAP) {
+		for (uint32_t k = 0; k < cnt; ++k) hit(scratch[(size_t)k * stride + p]);
+	} else {
+		msl_walk(P, p, P.vl_rc2, hit);
+	}
+}
+
 __global__ void __launch_bounds__(MSG) k_msl_fill(ForceParams P, const uint32_t* __restrict__ off, const uint32_t* __restrict__ hsrc,
 												  const uint8_t* __restrict__ hdir, uint32_t* __restrict__ out_j,
-												  uint8_t* __restrict__ out_il, int ncomp) {
+												  uint8_t* __restrict__ out_il, int ncomp, const uint32_t* __restrict__ scratch,
+												  const uint16_t* __restrict__ mcnt, uint32_t stride) {
 	__shared__ uint32_t cur[MSL_MAXT * MSG];  // [type][lane]
 	__shared__ uint32_t wsum[2];
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -124,9 +190,19 @@ __global__ void __launch_bounds__(MSG) k_msl_fill(ForceParams P, const uint32_t*
 	const uint32_t p = blockIdx.x * MSG + (uint32_t)tid;
 	const bool active = p < n_real;
 	const int ntypes = ncomp * ncomp;
-	for (int t = 0; t < ntypes; ++t) cur[t * MSG + tid] = 0;
 	const int ci = (active && ncomp > 1) ? P.cid[p] : 0;
-	if (active) msl_walk(P, p, P.vl_rc2, [&](uint32_t j) { cur[((ncomp > 1 ? ci * ncomp + P.cid[j] : 0)) * MSG + tid] += 1u; });
+	const uint32_t cnt = active ? (uint32_t)mcnt[p] : 0u;
+	if (ncomp > 1) {
+		for (int t = 0; t < ntypes; ++t) cur[t * MSG + tid] = 0;
+		if (active) msl_hits(P, p, cnt, scratch, stride, [&](uint32_t j) { cur[(ci * ncomp + P.cid[j]) * MSG + tid] += 1u; });
+	} else {
+		uint32_t n = cnt;
+		if (active && cnt > (uint32_t)MSL_CAP) {  // (the 16-bit tally saturates: count again)
+			n = 0;
+			msl_walk(P, p, P.vl_rc2, [&](uint32_t) { ++n; });
+		}
+		cur[tid] = n;
+	}
 	__syncthreads();
 	// type-major exclusive scan: cursor[t][lane] = pairs of all earlier types + pairs of type t of earlier lanes
 	uint32_t run = 0;
@@ -146,7 +222,7 @@ __global__ void __launch_bounds__(MSG) k_msl_fill(ForceParams P, const uint32_t*
 	}
 	const uint32_t total = run, padded = (total + 63u) & ~63u, o0 = off[blockIdx.x];
 	if (active)
-		msl_walk(P, p, P.vl_rc2, [&](uint32_t j) {
+		msl_hits(P, p, cnt, scratch, stride, [&](uint32_t j) {
 			const int t = ncomp > 1 ? ci * ncomp + P.cid[j] : 0;
 			const uint32_t at = o0 + cur[t * MSG + tid]++;
 			uint32_t e = j | (13u << 27);
@@ -163,10 +239,30 @@ __global__ void __launch_bounds__(MSG) k_msl_fill(ForceParams P, const uint32_t*
 	}
 }
 
+// ---- per step: one 64-byte record per owned molecule {x, y, z, q0, q1, q2, q3 (normalised), component id} ---------------------------
+// (FullMolecule::setupSoACache normalises q before rotating, FullMolecule.cpp:720 — done here once per molecule and step)
+__global__ void __launch_bounds__(256) k_msl_pack(ForceParams P, double* __restrict__ pk, int with_rot, int ncomp) {
+	const uint32_t n_real = P.n_fixed ? P.n_fixed : P.cnt->n_real;
+	const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+	if (p >= n_real) return;
+	double w = 1., x = 0., y = 0., z = 0.;
+	if (with_rot) {
+		w = P.q0[p]; x = P.q1[p]; y = P.q2[p]; z = P.q3[p];
+		const double inv = 1. / sqrt(w * w + x * x + y * y + z * z);
+		w *= inv; x *= inv; y *= inv; z *= inv;
+	}
+	double2* const rec = reinterpret_cast<double2*>(pk + (size_t)8 * p);
+	rec[0] = make_double2(P.x[p], P.y[p]);
+	rec[1] = make_double2(P.z[p], w);
+	rec[2] = make_double2(x, y);
+	rec[3] = make_double2(z, __hiloint2double(0, ncomp > 1 ? P.cid[p] : 0));
+}
+
 // ---- REUSE: forces from the pair stream, one wave per group ----------------------------------------------------------------------
 template <bool WITH_ROT>
 __global__ void __launch_bounds__(64) k_force_ms_list(ForceParams P, const uint32_t* __restrict__ off, const uint32_t* __restrict__ pj,
-													  const uint8_t* __restrict__ pil, const double* __restrict__ shift27) {
+													  const uint8_t* __restrict__ pil, const double* __restrict__ shift27,
+													  const double* __restrict__ pk, const CompTable* __restrict__ ctab) {
 	__shared__ double sr[3][MSG];
 	__shared__ double sq[WITH_ROT ? 4 : 1][MSG];
 	__shared__ int sci[MSG];
@@ -175,24 +271,27 @@ __global__ void __launch_bounds__(64) k_force_ms_list(ForceParams P, const uint3
 	const int lane = threadIdx.x;
 	const uint32_t n_real = P.n_fixed ? P.n_fixed : P.cnt->n_real;
 	const uint32_t p0 = blockIdx.x * MSG;
-	const CompTable& ct = *P.ct;
+	// the component table as its OWN restrict-qualified kernel argument: its loads are then provably not clobbered by the force
+	// stores and, the component indices being wave-uniform, become scalar loads (through P.ct they were ~60 dependent vector
+	// loads per trip — that, not the arithmetic, was the trip time of the first versions)
+	typedef const CompTable __attribute__((address_space(4))) ConstCompTable;  // constant address space: invariant for the launch
+	ConstCompTable& ct = *(ConstCompTable*)(uintptr_t)ctab;
 	const int ncomp = ct.ncomp;
 	for (int k = lane; k < MSG; k += 64) {
 		const uint32_t p = p0 + (uint32_t)k;
 		const bool ok = p < n_real;
-		sr[0][k] = ok ? P.x[p] : 0.;
-		sr[1][k] = ok ? P.y[p] : 0.;
-		sr[2][k] = ok ? P.z[p] : 0.;
+		const double2* const rec = reinterpret_cast<const double2*>(pk + (size_t)8 * (ok ? p : 0u));
+		const double2 d0 = rec[0], d1 = rec[1], d2 = rec[2], d3 = rec[3];
+		sr[0][k] = d0.x;
+		sr[1][k] = d0.y;
+		sr[2][k] = d1.x;
 		if (WITH_ROT) {
-			// FullMolecule::setupSoACache normalises q before rotating (FullMolecule.cpp:720)
-			double w = ok ? P.q0[p] : 1., x = ok ? P.q1[p] : 0., y = ok ? P.q2[p] : 0., z = ok ? P.q3[p] : 0.;
-			const double inv = 1. / sqrt(w * w + x * x + y * y + z * z);
-			sq[0][k] = w * inv;
-			sq[1][k] = x * inv;
-			sq[2][k] = y * inv;
-			sq[3][k] = z * inv;
+			sq[0][k] = d1.y;
+			sq[1][k] = d2.x;
+			sq[2][k] = d2.y;
+			sq[3][k] = d3.x;
 		}
-		sci[k] = (ok && ncomp > 1) ? P.cid[p] : 0;
+		sci[k] = (ok && ncomp > 1) ? (int)__double2loint(d3.y) : 0;
 		for (int a = 0; a < (WITH_ROT ? 6 : 3); ++a) acc[a][k] = 0.;
 	}
 	for (int k = lane; k < 81; k += 64) ssh[k] = shift27[k];
@@ -204,35 +303,69 @@ __global__ void __launch_bounds__(64) k_force_ms_list(ForceParams P, const uint3
 	a.Vi = {0., 0., 0.};
 	a.u6 = a.uX = a.rf = a.vir = 0.;
 	const uint32_t b0 = off[blockIdx.x], b1 = off[blockIdx.x + 1];
-	// the next trip's pair record is requested before the current trip's bodies run
-	uint32_t e = 0u | (13u << 27);
-	uint32_t il = 0xffu;
-	if (b0 < b1) {
-		e = pj[b0 + lane];
-		il = pil[b0 + lane];
-	}
-	for (uint32_t b = b0; b < b1; b += 64u) {
-		const uint32_t e_now = e, il_now = il;
-		if (b + 64u < b1) {
-			e = pj[b + 64u + lane];
-			il = pil[b + 64u + lane];
+	// Software pipeline, two trips deep: the pair record of trip t + 2 and the partner's packed state of trip t + 1 are requested
+	// before the bodies of trip t run — the gathers go through L2 / HBM, and at two waves per SIMD (the register budget of the
+	// molecule-pair body) nothing else hides their latency.  The partner's state is ONE 64-byte record (k_msl_pack): gathered
+	// from eight separate arrays every lane pulled eight cache lines through the L1 for 60 useful bytes, and the L2 -> L1 fill
+	// rate (64 B / clk / CU), not the arithmetic, set the pace (first version: VALU 41 % busy).
+	// (the loaded words are carried RAW into the next trip: any arithmetic on them here — the periodic shift, a conversion —
+	// would make the wave wait for the gather before the bodies of the current trip instead of behind them)
+	struct Partner {
+		uint32_t il, sh;
+		double2 d0, d1, d2, d3;
+	};
+	auto load_record = [&](uint32_t b, uint32_t& e, uint32_t& il) {
+		e = 0u | (13u << 27);
+		il = 0xffu;
+		if (b < b1) {
+			e = pj[b + lane];
+			il = pil[b + lane];
 		}
-		const bool valid = il_now != 0xffu;
-		const uint32_t j = e_now & MSL_IDX, sh = e_now >> 27, k = valid ? il_now : 0u;
+	};
+	auto load_partner = [&](uint32_t e, uint32_t il) {
+		Partner n;
+		const double2* const rec = reinterpret_cast<const double2*>(pk + (size_t)8 * (e & MSL_IDX));
+		n.d0 = rec[0];
+		n.d1 = rec[1];
+		n.d2 = rec[2];
+		n.d3 = rec[3];
+		n.il = il;
+		n.sh = e >> 27;
+		return n;
+	};
+	uint32_t e2, il2;
+	load_record(b0, e2, il2);
+	Partner nxt = load_partner(e2, il2);
+	load_record(b0 + 64u, e2, il2);
+	for (uint32_t b = b0; b < b1; b += 64u) {
+		const Partner raw = nxt;
+		nxt = load_partner(e2, il2);          // trip t + 1 (a padding record past the end: molecule 0, never evaluated)
+		load_record(b + 128u, e2, il2);        // trip t + 2
+		struct {
+			uint32_t il;
+			double x, y, z, q0, q1, q2, q3;
+			int cj;
+		} cur;
+		cur.il = raw.il;
+		cur.x = raw.d0.x + ssh[3 * raw.sh];
+		cur.y = raw.d0.y + ssh[3 * raw.sh + 1];
+		cur.z = raw.d1.x + ssh[3 * raw.sh + 2];
+		cur.q0 = raw.d1.y; cur.q1 = raw.d2.x; cur.q2 = raw.d2.y; cur.q3 = raw.d3.x;
+		cur.cj = (int)__double2loint(raw.d3.y);
+		const bool valid = cur.il != 0xffu;
+		const uint32_t k = valid ? cur.il : 0u;
 		const V3 ri = {sr[0][k], sr[1][k], sr[2][k]};
-		const V3 rj = {P.x[j] + ssh[3 * sh], P.y[j] + ssh[3 * sh + 1], P.z[j] + ssh[3 * sh + 2]};
+		const V3 rj = {cur.x, cur.y, cur.z};
 		const V3 drm = ri - rj;
 		const double dd = dot(drm, drm);
 		const bool in = valid && dd < rc2 && dd != 0.;
 		int tkey = 0;
 		Rot Ri = rot_of(1., 0., 0., 0.), Rj = Ri;
 		if (in) {
-			if (ncomp > 1) tkey = sci[k] * MAXC + P.cid[j];
+			if (ncomp > 1) tkey = sci[k] * MAXC + cur.cj;
 			if (WITH_ROT) {
 				Ri = rot_of(sq[0][k], sq[1][k], sq[2][k], sq[3][k]);
-				double w = P.q0[j], x = P.q1[j], y = P.q2[j], z = P.q3[j];
-				const double inv = 1. / sqrt(w * w + x * x + y * y + z * z);
-				Rj = rot_of(w * inv, x * inv, y * inv, z * inv);
+				Rj = rot_of(cur.q0, cur.q1, cur.q2, cur.q3);  // (normalised by k_msl_pack)
 			}
 		}
 		a.F = {0., 0., 0.};
@@ -244,7 +377,13 @@ __global__ void __launch_bounds__(64) k_force_ms_list(ForceParams P, const uint3
 			const int first = __ffsll((long long)todo) - 1;
 			const int t = __builtin_amdgcn_readlane(tkey, first);
 			const bool mine = in && tkey == t;
-			if (mine) mol_pair<false>(ct, t / MAXC, ri, Ri, t % MAXC, rj, Rj, drm, dd < rclj2, 0.5, a);
+			if (mine) {
+				// every active lane holds the same component pair: read it back as a SCALAR inside the branch (written as t / MAXC
+				// the compiler substitutes the lane's own key — it knows tkey == t here — and every table load behind it becomes a
+				// per-lane vector load with its own latency chain)
+				const int ci_u = __builtin_amdgcn_readfirstlane(tkey) / MAXC, cj_u = __builtin_amdgcn_readfirstlane(tkey) % MAXC;
+				mol_pair<false>(ct, ci_u, ri, Ri, cj_u, rj, Rj, drm, dd < rclj2, 0.5, a);
+			}
 			todo &= ~__ballot(mine);
 		}
 		if (in) {
@@ -285,28 +424,32 @@ __global__ void __launch_bounds__(64) k_force_ms_list(ForceParams P, const uint3
 // ---- host side ------------------------------------------------------------------------------------------------------------------
 uint32_t msl_groups(uint32_t n_real) { return (n_real + MSG - 1) / MSG; }
 
-void launch_msl_count(const ForceParams& p, uint32_t* grp_cnt, uint32_t* off, hipStream_t s) {
+int msl_capture_cap() { return MSL_CAP; }
+
+void launch_msl_count(const ForceParams& p, uint32_t* grp_cnt, uint32_t* off, uint32_t* scratch, uint16_t* mcnt, uint32_t stride,
+					  hipStream_t s) {
 	const uint32_t ng = msl_groups(p.n_real_cap);
 	if (ng == 0) return;
-	hipLaunchKernelGGL(k_msl_count, dim3(ng), dim3(MSG), 0, s, p, grp_cnt);
+	hipLaunchKernelGGL(k_msl_count, dim3(ng), dim3(MSG), 0, s, p, grp_cnt, scratch, mcnt, stride);
 	hipLaunchKernelGGL(k_msl_scan, dim3(1), dim3(1024), 0, s, grp_cnt, ng, off, p.cnt);
 }
 
 void launch_msl_fill(const ForceParams& p, const uint32_t* off, const uint32_t* hsrc, const uint8_t* hdir, uint32_t* out_j,
-					 uint8_t* out_il, int ncomp, hipStream_t s) {
+					 uint8_t* out_il, int ncomp, const uint32_t* scratch, const uint16_t* mcnt, uint32_t stride, hipStream_t s) {
 	const uint32_t ng = msl_groups(p.n_real_cap);
 	if (ng == 0) return;
-	hipLaunchKernelGGL(k_msl_fill, dim3(ng), dim3(MSG), 0, s, p, off, hsrc, hdir, out_j, out_il, ncomp);
+	hipLaunchKernelGGL(k_msl_fill, dim3(ng), dim3(MSG), 0, s, p, off, hsrc, hdir, out_j, out_il, ncomp, scratch, mcnt, stride);
 }
 
-bool launch_force_ms_list(const ForceParams& p, bool has_rot, const uint32_t* off, const uint32_t* pj, const uint8_t* pil,
-						  const double* shift27, hipStream_t s, uint32_t* nblocks, size_t partials_cap) {
+bool launch_force_ms_list(const ForceParams& p, bool has_rot, int ncomp, const uint32_t* off, const uint32_t* pj, const uint8_t* pil,
+						  const double* shift27, double* pk, hipStream_t s, uint32_t* nblocks, size_t partials_cap) {
 	const uint32_t ng = msl_groups(p.n_real_cap);
 	if ((size_t)ng > partials_cap || p.which != 0) return false;
 	*nblocks = ng;
 	if (ng == 0) return true;
-	if (has_rot) hipLaunchKernelGGL((k_force_ms_list<true>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27);
-	else hipLaunchKernelGGL((k_force_ms_list<false>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27);
+	hipLaunchKernelGGL(k_msl_pack, dim3((p.n_real_cap + 255u) / 256u), dim3(256), 0, s, p, pk, has_rot ? 1 : 0, ncomp);
+	if (has_rot) hipLaunchKernelGGL((k_force_ms_list<true>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);
+	else hipLaunchKernelGGL((k_force_ms_list<false>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);
 	return true;
 }
 

@@ -31,13 +31,18 @@ struct MolAcc {
 	double u6, uX, rf, vir;
 };
 
-LS1_HD V3 ld3(const double (*t)[3], int k) { return {t[k][0], t[k][1], t[k][2]}; }
+template <class T3>
+LS1_HD V3 ld3(const T3& t, int k) {  // t: double [n][3] in any address space
+	return {t[k][0], t[k][1], t[k][2]};
+}
 
 // Accumulate on molecule i everything molecule j does to it.  drm = r_i - r_j (centres); calcLJ per
 // VectorizedCellProcessor.cpp:967-968,1013-1024 (LJ uses the LJ cutoff on the CENTRE distance).
 // w = weight of the pair's macroscopic contribution seen from i (0.5 in full-shell mode).
-template <bool WITH_VI>
-LS1_HD void mol_pair(const CompTable& ct, int ci, V3 ri, const Rot& Ri, int cj, V3 rj, const Rot& Rj, V3 drm,
+// CT: CompTable in any address space (kernels_force_mslist.hip reads it through the constant address space, so that the
+// table loads behind its wave-uniform component indices become scalar loads)
+template <bool WITH_VI, class CT = CompTable>
+LS1_HD void mol_pair(const CT& ct, int ci, V3 ri, const Rot& Ri, int cj, V3 rj, const Rot& Rj, V3 drm,
 					 bool calcLJ, double w, MolAcc& a) {
 	V3 Fp = {0., 0., 0.};  // force on i from this pair (for the virial)
 	double u6 = 0., uX = 0., rf = 0.;

@@ -22,6 +22,18 @@
 #endif
 #endif
 
+// Reciprocal and square root of the pair bodies.  Default: IEEE division / sqrt (what the generic and the brick kernels use:
+// their results are bitwise equal to each other, and the host shim compiles the same expressions).  A translation unit may
+// define LS1_PAIR_RCP / LS1_PAIR_SQRT before including this header to trade the last bit for instruction count
+// (kernels_force_mslist.hip: v_rcp_f64 / v_rsq_f64 with two Newton steps, 1.1e-16 relative — an IEEE division is ~28
+// instructions of a 60-instruction LJ site pair).
+#ifndef LS1_PAIR_RCP
+#define LS1_PAIR_RCP(x) (1. / (x))
+#endif
+#ifndef LS1_PAIR_SQRT
+#define LS1_PAIR_SQRT(x) sqrt(x)
+#endif
+
 namespace ls1 {
 
 struct V3 {
@@ -66,7 +78,7 @@ LS1_HD V3 rotate_inv(const Rot& R, V3 d) {
 // ---- LJ 12-6: potforce.h:18-30 / VectorizedCellProcessor::_loopBodyLJ (VectorizedCellProcessor.cpp:173-226).
 // dr = r_i - r_j (sites).  f = force on i.  u6 = 6*U (without shift).
 LS1_HD void lj(V3 dr, double dr2, double eps24, double sig2, V3& f, double& u6) {
-	const double ir2 = 1. / dr2;
+	const double ir2 = LS1_PAIR_RCP(dr2);
 	double lj6 = sig2 * ir2;
 	lj6 = lj6 * lj6 * lj6;
 	const double lj12 = lj6 * lj6;
@@ -78,8 +90,8 @@ LS1_HD void lj(V3 dr, double dr2, double eps24, double sig2, V3& f, double& u6) 
 
 // ---- charge-charge: potforce.h:190-199.
 LS1_HD void charge_charge(V3 dr, double dr2, double q1q2, V3& f, double& u) {
-	const double ir2 = 1.0 / dr2;
-	const double ir1 = sqrt(ir2);
+	const double ir2 = LS1_PAIR_RCP(dr2);
+	const double ir1 = LS1_PAIR_SQRT(ir2);
 	u = q1q2 * ir1;
 	f = (u * ir2) * dr;
 }
@@ -87,8 +99,8 @@ LS1_HD void charge_charge(V3 dr, double dr2, double q1q2, V3& f, double& u) {
 // ---- charge (site a) - dipole (site b): potforce.h:237-263.  dr = r_a - r_b, e = dipole axis,
 // neg_q_my = -q*my.  fa = force on the charge; mb = torque on the dipole.
 LS1_HD void charge_dipole(V3 dr, double dr2, V3 e, double neg_q_my, V3& fa, V3& mb, double& u) {
-	const double ir2 = 1.0 / dr2;
-	const double ir1 = sqrt(ir2);
+	const double ir2 = LS1_PAIR_RCP(dr2);
+	const double ir1 = LS1_PAIR_SQRT(ir2);
 	const double cb = dot(e, dr) * ir1;
 	const double k_cd = neg_q_my * ir2;
 	u = k_cd * cb;
@@ -100,8 +112,8 @@ LS1_HD void charge_dipole(V3 dr, double dr2, V3 e, double neg_q_my, V3& fa, V3& 
 
 // ---- charge (a) - quadrupole (b): potforce.h:205-231.  half_qQ = 0.5*q*Q.
 LS1_HD void charge_quadrupole(V3 dr, double dr2, V3 e, double half_qQ, V3& fa, V3& mb, double& u) {
-	const double ir2 = 1.0 / dr2;
-	const double ir1 = sqrt(ir2);
+	const double ir2 = LS1_PAIR_RCP(dr2);
+	const double ir1 = LS1_PAIR_SQRT(ir2);
 	const double cb = dot(e, dr) * ir1;
 	const double w_cq = half_qQ * ir1 * ir2;
 	u = w_cq * (3.0 * cb * cb - 1);
@@ -116,8 +128,8 @@ LS1_HD void charge_quadrupole(V3 dr, double dr2, V3 e, double half_qQ, V3& fa, V
 // rf = reaction-field energy contribution of the pair (MyRF -= rffac*cos gamma).
 LS1_HD void dipole_dipole(V3 dr, double dr2, V3 ei, V3 ej, double my2, double rffac, V3& f, V3& mi, V3& mj, double& u,
 						  double& rf) {
-	const double ir2 = 1. / dr2;
-	const double ir1 = sqrt(ir2);
+	const double ir2 = LS1_PAIR_RCP(dr2);
+	const double ir1 = LS1_PAIR_SQRT(ir2);
 	const double w_dd = my2 * ir2 * ir1;
 	double ca = dot(ei, dr), cb = dot(ej, dr);
 	const double cg = dot(ei, ej);
@@ -138,8 +150,8 @@ LS1_HD void dipole_dipole(V3 dr, double dr2, V3 ei, V3 ej, double my2, double rf
 
 // ---- quadrupole (i) - quadrupole (j): potforce.h:86-133.  qq075 = 0.75*Qi*Qj.
 LS1_HD void quadrupole_quadrupole(V3 dr, double dr2, V3 ei, V3 ej, double qq075, V3& f, V3& mi, V3& mj, double& u) {
-	const double ir2 = 1. / dr2;
-	const double ir1 = sqrt(ir2);
+	const double ir2 = LS1_PAIR_RCP(dr2);
+	const double ir1 = LS1_PAIR_SQRT(ir2);
 	const double w_qq = qq075 * ir2 * ir2 * ir1;
 	double ca = dot(ei, dr), cb = dot(ej, dr);
 	const double cg = dot(ei, ej);
@@ -162,8 +174,8 @@ LS1_HD void quadrupole_quadrupole(V3 dr, double dr2, V3 ei, V3 ej, double qq075,
 // ---- dipole (a) - quadrupole (b): potforce.h:139-184.  dr = r_a - r_b.  dq15 = 1.5*my*Q.
 // f = force on the dipole site, ma / mb torques on dipole / quadrupole.
 LS1_HD void dipole_quadrupole(V3 dr, double dr2, V3 ea, V3 eb, double dq15, V3& f, V3& ma, V3& mb, double& u) {
-	const double ir2 = 1. / dr2;
-	const double ir1 = sqrt(ir2);
+	const double ir2 = LS1_PAIR_RCP(dr2);
+	const double ir1 = LS1_PAIR_SQRT(ir2);
 	const double w_dq = dq15 * ir2 * ir2;
 	double ca = dot(ea, dr), cb = dot(eb, dr);
 	const double cg = dot(ea, eb);

@@ -121,6 +121,14 @@ struct CartDecomp {
 	}
 };
 
+// ---- transport interface (duck-typed; HaloExchangerT / DecomposedLoopT are templates over it) ----------------------------------
+//   int world(), rank();  std::vector<int64_t> all_gather(const int64_t* mine, int n);  void all_reduce(double* v, int n, ReduceOp);
+//   void group_start(); void send(const double* dev, size_t count, int peer); void recv(double* dev, size_t count, int peer);
+//   void group_end();   // returns when every transfer of the group has completed
+// Implementations: RcclTransport (below: xGMI, one GPU per rank) and MailboxTransport (MailboxTransport.hpp: host-staged, any
+// number of ranks per GPU — tests, and hosts without a fabric).
+enum class ReduceOp { Sum, Max };
+
 // ---- transport: one RCCL communicator, its own stream --------------------------------------------------------------------
 class RcclTransport {
 public:
@@ -159,6 +167,7 @@ public:
 	~RcclTransport() {
 		if (_comm) ncclCommDestroy(_comm);
 		if (_d_small) (void)hipFree(_d_small);
+		if (_d_bytes) (void)hipFree(_d_bytes);
 		if (_h_small) (void)hipHostFree(_h_small);
 		if (_stream) (void)hipStreamDestroy(_stream);
 	}
@@ -182,6 +191,37 @@ public:
 		sync();
 		return std::vector<int64_t>(h, h + (size_t)_world * n);
 	}
+	void all_reduce(double* v, int n, ReduceOp op) { all_reduce(v, n, op == ReduceOp::Sum ? ncclSum : ncclMax); }
+	// [world][n] table of every rank's n bytes (the reference's typed collectives: DomainDecompHip::collComm*)
+	void all_gather_bytes(const void* mine, size_t n, std::vector<char>& all) {
+		all.assign((size_t)_world * n, 0);
+		if (_world == 1) {
+			std::memcpy(all.data(), mine, n);
+			return;
+		}
+		const size_t need = n * ((size_t)_world + 1);
+		if (need > _bytes_cap) {
+			if (_d_bytes) (void)hipFree(_d_bytes);
+			_bytes_cap = need + 4096;
+			LS1_HIPCHECK(hipMalloc(&_d_bytes, _bytes_cap));
+		}
+		char* d = static_cast<char*>(_d_bytes);
+		LS1_HIPCHECK(hipMemcpyAsync(d, mine, n, hipMemcpyHostToDevice, _stream));
+		LS1_NCCLCHECK(ncclAllGather(d, d + n, n, ncclChar, _comm, _stream));
+		LS1_HIPCHECK(hipMemcpyAsync(all.data(), d + n, (size_t)_world * n, hipMemcpyDeviceToHost, _stream));
+		sync();
+	}
+	void barrier() {
+		double v = 0.;
+		all_reduce(&v, 1, ncclSum);
+	}
+	void group_start() { LS1_NCCLCHECK(ncclGroupStart()); }
+	void send(const double* dev, size_t count, int peer) { LS1_NCCLCHECK(ncclSend(dev, count, ncclDouble, peer, _comm, _stream)); }
+	void recv(double* dev, size_t count, int peer) { LS1_NCCLCHECK(ncclRecv(dev, count, ncclDouble, peer, _comm, _stream)); }
+	void group_end() {
+		LS1_NCCLCHECK(ncclGroupEnd());
+		sync();
+	}
 	// in-place sum / max of n <= 16 doubles
 	void all_reduce(double* v, int n, ncclRedOp_t op) {
 		if (_world == 1) return;
@@ -201,15 +241,18 @@ private:
 	ncclComm_t _comm = nullptr;
 	void* _d_small = nullptr;
 	void* _h_small = nullptr;
+	void* _d_bytes = nullptr;
+	size_t _bytes_cap = 0;
 };
 
 // ---- per-peer merged exchange of packed records --------------------------------------------------------------------------
-class HaloExchangerRccl {
+template <class TR>
+class HaloExchangerT {
 public:
 	enum Kind { LEAVING = 0, HALO = 1, REFRESH = 2 };
 	static int record_doubles(int kind) { return kind == LEAVING ? LS1HIP_LEAVING_DOUBLES : kind == HALO ? LS1HIP_HALO_DOUBLES : LS1HIP_REFRESH_DOUBLES; }
 
-	HaloExchangerRccl(const CartDecomp& dc, ls1hip_ctx* ctx, RcclTransport& tr) : _dc(dc), _ctx(ctx), _tr(tr) {
+	HaloExchangerT(const CartDecomp& dc, ls1hip_ctx* ctx, TR& tr) : _dc(dc), _ctx(ctx), _tr(tr) {
 		_dc.neighbor_table(_nbr);
 		_peers = _dc.peers();
 		for (int p : _peers) {
@@ -224,7 +267,7 @@ public:
 			}
 		}
 	}
-	~HaloExchangerRccl() {
+	~HaloExchangerT() {
 		if (_sbuf) (void)hipFree(_sbuf);
 		if (_rbuf) (void)hipFree(_rbuf);
 	}
@@ -292,16 +335,15 @@ private:
 		}
 		if (tot_in) reserve(&_rbuf, &_rcap, tot_in * w * sizeof(double));
 		if (tot_out || tot_in) {
-			LS1_NCCLCHECK(ncclGroupStart());
+			_tr.group_start();
 			size_t so = 0, ro = 0;
 			for (int p : _peers) {
-				if (n_out[p]) LS1_NCCLCHECK(ncclSend(static_cast<double*>(_sbuf) + so * w, n_out[p] * w, ncclDouble, _dc.real_rank(p), _tr.comm(), _tr.stream()));
-				if (n_in[p]) LS1_NCCLCHECK(ncclRecv(static_cast<double*>(_rbuf) + ro * w, n_in[p] * w, ncclDouble, _dc.real_rank(p), _tr.comm(), _tr.stream()));
+				if (n_out[p]) _tr.send(static_cast<double*>(_sbuf) + so * w, n_out[p] * w, _dc.real_rank(p));
+				if (n_in[p]) _tr.recv(static_cast<double*>(_rbuf) + ro * w, n_in[p] * w, _dc.real_rank(p));
 				so += n_out[p];
 				ro += n_in[p];
 			}
-			LS1_NCCLCHECK(ncclGroupEnd());
-			_tr.sync();
+			_tr.group_end();
 		}
 		if (tot_in && ls1hip_import(_ctx, kind, _rbuf, tot_in) != LS1HIP_OK && _deferred.empty()) _deferred = ls1hip_last_error(_ctx);
 		if (ls1hip_import_done(_ctx, kind) != LS1HIP_OK) {
@@ -312,7 +354,7 @@ private:
 
 	const CartDecomp& _dc;
 	ls1hip_ctx* _ctx;
-	RcclTransport& _tr;
+	TR& _tr;
 	int _nbr[27];
 	std::vector<int> _peers;
 	std::map<int, std::vector<int>> _incoming, _outgoing;
@@ -323,22 +365,27 @@ private:
 	size_t _scap = 0, _rcap = 0;
 };
 
+using HaloExchangerRccl = HaloExchangerT<RcclTransport>;
+
 // ---- one rank of the decomposed time loop ----------------------------------------------------------------------------------
 struct GlobalValues {
 	double upot = 0., virial = 0., summv2 = 0., sumIw2 = 0.;
 	uint64_t n = 0, rot_dof = 0;
 };
 
-class DecomposedLoop {
+template <class TR>
+class DecomposedLoopT {
+	using Ex = HaloExchangerT<TR>;
+
 public:
-	DecomposedLoop(const CartDecomp& dc, ls1hip_ctx* ctx, RcclTransport& tr) : _ctx(ctx), _tr(tr), _ex(dc, ctx, tr) {}
+	DecomposedLoopT(const CartDecomp& dc, ls1hip_ctx* ctx, TR& tr) : _ctx(ctx), _tr(tr), _ex(dc, ctx, tr) {}
 
 	GlobalValues initial_forces() {
 		chk(ls1hip_rebin(_ctx), "ls1hip_rebin");
-		_ex.exchange(HaloExchangerRccl::LEAVING);
+		_ex.exchange(Ex::LEAVING);
 		chk(ls1hip_forces(_ctx, 1, nullptr, nullptr), "ls1hip_forces");
 		chk(ls1hip_halo(_ctx), "ls1hip_halo");
-		_ex.exchange(HaloExchangerRccl::HALO);
+		_ex.exchange(Ex::HALO);
 		double u = 0., w = 0.;
 		chk(ls1hip_forces(_ctx, 2, &u, &w), "ls1hip_forces");
 		size_t n = 0, h = 0;
@@ -361,12 +408,12 @@ public:
 			advanced = fuse && !last;
 			// re-bin + migration, the inner traversal FIRST (owned molecules only), the whole halo phase while it computes
 			chk(ls1hip_rebin(_ctx), "ls1hip_rebin");
-			_ex.exchange(HaloExchangerRccl::LEAVING);
+			_ex.exchange(Ex::LEAVING);
 			double u = 0., w = 0.;
 			if (advanced) chk(ls1hip_forces_kick_drift(_ctx, 1, dt, nullptr, nullptr), "ls1hip_forces_kick_drift");
 			else chk(ls1hip_forces(_ctx, 1, nullptr, nullptr), "ls1hip_forces");
 			chk(ls1hip_halo(_ctx), "ls1hip_halo");
-			_ex.exchange(HaloExchangerRccl::HALO);
+			_ex.exchange(Ex::HALO);
 			if (advanced) chk(ls1hip_forces_kick_drift(_ctx, 2, dt, nullptr, nullptr), "ls1hip_forces_kick_drift");
 			else chk(ls1hip_forces(_ctx, 2, last ? &u : nullptr, last ? &w : nullptr), "ls1hip_forces");
 			if (last) out = finish(dt, u, w);
@@ -389,9 +436,9 @@ public:
 			double u = 0., w = 0.;
 			if (rebuild) {
 				chk(ls1hip_rebin(_ctx), "ls1hip_rebin");
-				_ex.exchange(HaloExchangerRccl::LEAVING);
+				_ex.exchange(Ex::LEAVING);
 				chk(ls1hip_halo(_ctx), "ls1hip_halo");
-				_ex.exchange(HaloExchangerRccl::HALO);
+				_ex.exchange(Ex::HALO);
 				chk(ls1hip_verlet_build(_ctx), "ls1hip_verlet_build");
 				chk(ls1hip_forces_list(_ctx, 0, fdt, last ? &u : nullptr, last ? &w : nullptr), "ls1hip_forces_list");
 			} else {
@@ -408,7 +455,7 @@ public:
 	// Domain::calculateGlobalValues: one all-reduce of {U_pot, virial, sum m v^2, sum I w^2, N, rotDOF} + the error status
 	GlobalValues reduce_globals(double upot, double virial, double summv2, double sumIw2, uint64_t n, uint64_t rot_dof) {
 		double v[7] = {upot, virial, summv2, sumIw2, (double)n, (double)rot_dof, _ex.has_deferred_error() ? 1. : 0.};
-		_tr.all_reduce(v, 7, ncclSum);
+		_tr.all_reduce(v, 7, ReduceOp::Sum);
 		if (v[6] != 0.)
 			throw DecompositionError(std::to_string((int)v[6]) + " rank(s) reported an engine error in the last exchange" +
 									 (_ex.has_deferred_error() ? "; this rank: " + _ex.deferred_error() : ""));
@@ -433,13 +480,14 @@ private:
 		int need = 0;
 		chk(ls1hip_verlet_poll(_ctx, &need), "ls1hip_verlet_poll");
 		double v = need ? 1. : 0.;
-		_tr.all_reduce(&v, 1, ncclMax);
+		_tr.all_reduce(&v, 1, ReduceOp::Max);
 		return v > 0.;
 	}
 
 	ls1hip_ctx* _ctx;
-	RcclTransport& _tr;
-	HaloExchangerRccl _ex;
+	TR& _tr;
+	Ex _ex;
 };
+using DecomposedLoop = DecomposedLoopT<RcclTransport>;
 
 }  // namespace ls1hip

@@ -29,6 +29,7 @@
 #include "utils/Logger.h"
 #include "utils/xmlfileUnits.h"
 
+#include "DomainDecompHip.h"
 #include "ls1hip_components.hpp"
 
 using Log::global_log;
@@ -181,14 +182,17 @@ void LinkedCellsHip::printSubInfo(int offset) { _mirror.printSubInfo(offset); }
 void LinkedCellsHip::uploadFromMirror() {
 	Simulation* sim = global_simulation;
 	Domain* domain = sim->getDomain();
-	if (sim->domainDecomposition().getNumProcs() != 1) {
-		global_log->error() << "LinkedCellsHip: this adapter serves the sequential / single-rank driver; multi-rank runs go "
-							   "through the export / import entry points of ls1hip.h (INTEGRATION.md)" << std::endl;
+	// multi-rank: the decomposition the driver constructed must be the device-side one (seam_b_register.h maps it); it supplies
+	// the rank grid, this rank's neighbours and the transport (RCCL over xGMI, or the host-staged mailbox)
+	DomainDecompHip* dd = dynamic_cast<DomainDecompHip*>(&sim->domainDecomposition());
+	_multiRank = sim->domainDecomposition().getNumProcs() > 1;
+	if (_multiRank && !dd) {
+		global_log->error() << "LinkedCellsHip: a multi-rank run needs DomainDecompHip (seam_b_register.h / INTEGRATION.md)" << std::endl;
 		Simulation::exit(681);
 	}
 	int rc;
 	if (!_ctx) {
-		int device = 0;
+		int device = dd ? dd->localDevice() : 0;
 		if (const char* e = getenv("LS1HIP_DEVICE")) device = atoi(e);
 		if ((rc = ls1hip_create(device, &_ctx))) die("ls1hip_create", rc);
 	}
@@ -202,6 +206,7 @@ void LinkedCellsHip::uploadFromMirror() {
 	_skin = 0.08 * sim->getcutoffRadius();
 	if (const char* e = getenv("LS1HIP_SKIN")) _skin = atof(e);
 	if (_mirror.getHaloWidthNumCells() != 1) _skin = 0.;
+	if (_multiRank) _skin = 0.;  // the multi-rank seam of the driver searches every step (the list-mode exchange is the handed-over loop's)
 	if ((rc = ls1hip_set_verlet(_ctx, _skin > 0. ? 1 : 0, _skin))) die("ls1hip_set_verlet", rc);
 	double glen[3], bmin[3], bmax[3];
 	int nbr[27];
@@ -211,7 +216,8 @@ void LinkedCellsHip::uploadFromMirror() {
 		bmax[d] = _mirror.getBoundingBoxMax(d);
 	}
 	for (int k = 0; k < 27; ++k) nbr[k] = 0;  // DomainDecompBase: every side is periodic onto this rank
-	if ((rc = ls1hip_set_domain(_ctx, glen, bmin, bmax, 0, nbr))) die("ls1hip_set_domain", rc);
+	if (_multiRank) dd->neighbourTable(glen, nbr);
+	if ((rc = ls1hip_set_domain(_ctx, glen, bmin, bmax, _multiRank ? dd->getRank() : 0, nbr))) die("ls1hip_set_domain", rc);
 	std::vector<uint64_t> id;
 	std::vector<int32_t> cid;
 	std::vector<double> r, v, q, D;
@@ -241,10 +247,28 @@ void LinkedCellsHip::update() {
 		_mirror.update();
 		uploadFromMirror();
 	}
+	if (_multiRank) {
+		// classification only (leavers packed per direction); DomainDecompHip::balanceAndExchange moves them, then the halo copies
+		int rc = ls1hip_rebin(_ctx);
+		if (rc) die("ls1hip_rebin", rc);
+		_inExchange = true;
+		return;
+	}
 	// list-aware: re-bin + halo (+ list build), or — while the lists are alive — only a refresh of the halo positions
 	int rc = ls1hip_update(_ctx, nullptr);
 	if (rc) die("ls1hip_update", rc);
 	_inExchange = true;
+}
+
+// DomainDecompHip::balanceAndExchange (multi-rank): leaving molecules, halo generation, halo copies — the direct scheme of the
+// reference (NeighbourCommunicationScheme.cpp:115-136) over the export / import entry points
+void LinkedCellsHip::exchangeAcrossRanks(DomainDecompHip& dd, Domain* domain) {
+	double glen[3];
+	for (int d = 0; d < 3; ++d) glen[d] = domain->getGlobalLength(d);
+	dd.exchange(_ctx, glen, 0);
+	int rc = ls1hip_halo(_ctx);
+	if (rc) die("ls1hip_halo", rc);
+	dd.exchange(_ctx, glen, 1);
 }
 
 void LinkedCellsHip::updateMoleculeCaches() {

@@ -37,6 +37,7 @@
 #include "ls1hip.h"
 
 class Domain;
+class DomainDecompHip;
 
 class LinkedCellsHip : public ParticleContainer {
 public:
@@ -94,6 +95,7 @@ public:
 	void syncMirrorFromDevice(bool applyPendingBeta = false);
 	bool mirrorFresh() const { return _mirrorFresh; }
 	void stepClosed();                // eventForcesCalculated is through: only the thermostat's host loop follows in this step
+	void exchangeAcrossRanks(DomainDecompHip& dd, Domain* domain);  // multi-rank: leaving molecules + halo copies through dd's transport
 	void armPostForceKick(double dt_half) { _armedKick = dt_half; }  // the next complete traversal queues the kick behind itself
 	bool takeQueuedKick() {
 		const bool q = _kickQueued;
@@ -116,6 +118,7 @@ private:
 	bool _uploaded = false;     // the device holds the molecule set
 	bool _mirrorFresh = true;   // the mirror holds the current molecule set
 	bool _hostDirty = true;     // molecules were added / removed through the host interface since the last upload
+	bool _multiRank = false;    // more than one rank: update() only classifies, DomainDecompHip exchanges
 	bool _inExchange = false;   // between update() and updateMoleculeCaches(): the driver's exchangeMolecules window
 	bool _stepOpen = false;     // between eventNewTimestep and eventForcesCalculated
 	bool _quietArmed = false;   // after eventForcesCalculated until the driver advances the simulation time (thermostat loop)

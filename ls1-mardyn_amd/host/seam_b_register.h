@@ -6,11 +6,20 @@
 //     Simulation.cpp:422   _moleculeContainer = new LinkedCells();
 // are mapped to the device-resident classes of LinkedCellsHip.h.  The XML type strings ("LinkedCells", "Leapfrog") are
 // string literals and are not affected.  No reference source file is edited or copied.
+// Round 3, multi-rank seam: the third construction site
+//     Simulation.cpp:1356  _domainDecomposition = new DomainDecompBase();     (non-MPI build)
+// becomes `new DomainDecompHip()` through a FUNCTION-LIKE macro: it only fires where the name is followed by "(", i.e. at
+// that constructor call — declarations such as `DomainDecompBase* domainDecomposition` (Simulation.cpp:1321) keep the base
+// type.  The headers that declare the class are included first, under their real names.
 #pragma once
+#include "Simulation.h"
 #include "integrators/Leapfrog.h"
+#include "parallel/DomainDecompBase.h"
 #include "particleContainer/LinkedCells.h"
 
+#include "DomainDecompHip.h"
 #include "LinkedCellsHip.h"
 
 #define LinkedCells LinkedCellsHip
 #define Leapfrog LeapfrogHip
+#define DomainDecompBase(...) DomainDecompHip(__VA_ARGS__)

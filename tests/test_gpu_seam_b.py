@@ -83,8 +83,8 @@ def test_reference_driver_with_device_container_and_integrator(tmp_path, case):
     assert m
     if case == "1clj_generated":  # single-site LJ: the adapter's default is the list loop (skin 0.08 rc), rebuilt on demand
         assert m.group(1) == "on" and int(m.group(3)) >= steps and 1 <= int(m.group(2)) < steps
-    if case == "ethane_inp":      # multi-site: the engine keeps the search-every-step kernels by itself
-        assert int(m.group(3)) == 0
+    if case == "ethane_inp":      # multi-site (round 3): per-wave pair streams, the same default skin
+        assert m.group(1) == "on" and int(m.group(3)) >= steps and 1 <= int(m.group(2)) <= steps
     # the driver prints 6 significant digits
     assert np.allclose(hip[:n], ref[:n], rtol=2e-5, atol=1e-12), (ref[:n], hip[:n])
     # final checkpoint: written by the reference's writer iterating OUR container (mirror synced from the device)

@@ -1,0 +1,117 @@
+"""Multi-rank seam B: the decomposed path entered from the UNMODIFIED reference driver.
+
+oracle/_ref/MarDyn_hipB constructs `DomainDecompHip : public DomainDecompBase` at Simulation.cpp:1356 (mapped by
+ls1-mardyn_amd/host/seam_b_register.h) next to the device container and integrator.  Here 2 and 4 MarDyn_hipB PROCESSES
+(rank / world size from the environment, as any launcher exports them) share the one GPU of the test box through the
+host-staged mailbox transport (RCCL refuses two ranks on one device; on a multi-GPU node the same class runs RCCL over xGMI):
+each rank owns a sub-box of the regular rank grid (DomainDecomposition.cpp:114-123), reads the same phase-space file and keeps
+its own molecules, exchanges leaving molecules and halo copies per step through the export / import entry points, and takes
+part in every global reduction of the driver (Domain::calculateGlobalValues, Domain.cpp:151-181) through the collComm*
+virtuals.  Rank 0 must print the per-step T / U_pot / p of the unmodified single-process reference binary, and the union of the
+ranks' final checkpoints must hold the reference's molecules."""
+import gzip
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from golden_io import GOLDEN
+from test_gpu_seam_a import HEAD, LJ1, REF, _run
+from test_gpu_seam_b import HIPB, _restart_records
+
+pytestmark = pytest.mark.gpu
+
+
+def _launch_ranks(world, cfg_dir_of_rank, steps, comm_dir):
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, OMP_NUM_THREADS="2", RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", LS1HIP_DEVICE="0",
+                   LS1HIP_TRANSPORT="mailbox", LS1HIP_COMM_DIR=comm_dir)
+        procs.append(subprocess.Popen([HIPB, "config.xml", "--steps", str(steps), "--final-checkpoint=1"], cwd=cfg_dir_of_rank[r],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for r, p in enumerate(procs):
+        try:
+            o, e = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()  # exactly the processes started here
+            raise
+        outs.append((p.returncode, o, e))
+    for r, (rc, o, e) in enumerate(outs):
+        assert rc == 0, f"rank {r}: rc {rc}\n{o[-3000:]}\n{e[-2000:]}"
+    return outs
+
+
+@pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(HIPB)), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("world", [2, 4])
+def test_reference_driver_decomposed_over_ranks(tmp_path, world):
+    steps = 12
+    src = os.path.join(GOLDEN, "inputs", "synthetic_bcc1clj_20.inp.gz")  # 16 000 molecules, L = 27.3 sigma
+    with gzip.open(src, "rb") as fi, open(tmp_path / "bcc.inp", "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    L = None
+    with open(tmp_path / "bcc.inp") as fh:
+        for ln in fh:
+            if ln.strip().startswith("Length"):
+                L = float(ln.split()[1])
+                break
+    cfg = HEAD.format(dt=0.002, steps=steps, temp=0.95, L=repr(L), rc=2.5, components=LJ1,
+                      phasespace='<file type="ASCII">bcc.inp</file>')
+    # single-process reference
+    dref = tmp_path / "ref"
+    dref.mkdir()
+    shutil.copy(tmp_path / "bcc.inp", dref / "bcc.inp")
+    (dref / "config.xml").write_text(cfg)
+    ref_rows, _ = _run(REF, "config.xml", str(dref), steps, final_checkpoint=1)
+    # world ranks of the device build
+    dirs = []
+    for r in range(world):
+        d = tmp_path / f"rank{r}"
+        d.mkdir()
+        shutil.copy(tmp_path / "bcc.inp", d / "bcc.inp")
+        (d / "config.xml").write_text(cfg)
+        dirs.append(str(d))
+    comm = tempfile.mkdtemp(prefix="ls1hip_comm_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        outs = _launch_ranks(world, dirs, steps, comm)
+    finally:
+        shutil.rmtree(comm, ignore_errors=True)
+    log0 = outs[0][1]
+    assert f"DomainDecompHip: rank 0 of {world}" in log0 and "transport mailbox" in log0
+    rows = re.findall(r"Simstep = (\d+)\s+T = (\S+)\s+U_pot = (\S+)\s+p = (\S+)", log0)
+    hip_rows = np.array([[float(x) for x in r[1:]] for r in rows])
+    assert len(hip_rows) >= steps
+    # the driver prints 6 significant digits
+    assert np.allclose(hip_rows[:steps], ref_rows[:steps], rtol=2e-5, atol=1e-12), (ref_rows[:steps], hip_rows[:steps])
+    # every rank reports the same global values
+    for r in range(1, world):
+        rr = re.findall(r"Simstep = (\d+)\s+T = (\S+)\s+U_pot = (\S+)\s+p = (\S+)", outs[r][1])
+        assert [x[1:] for x in rr[:steps]] == [x[1:] for x in rows[:steps]], r
+    # final checkpoints: the union of the ranks' molecules == the reference's, every molecule exactly once
+    fr = [f for f in os.listdir(dref) if f.endswith(".restart.dat")]
+    assert fr
+    a = _restart_records(dref / fr[0])
+    b = {}
+    per_rank = []
+    for d in dirs:
+        f = [x for x in os.listdir(d) if x.endswith(".restart.dat")]
+        assert f, d
+        recs = _restart_records(os.path.join(d, f[0]))
+        assert not (recs.keys() & b.keys()), "a molecule is owned by two ranks"
+        b.update(recs)
+        per_rank.append(len(recs))
+    assert a.keys() == b.keys() and len(a) == 16000
+    assert all(n > 0 for n in per_rank)
+    ids = sorted(a)
+    A, B = np.array([a[i] for i in ids]), np.array([b[i] for i in ids])
+    dr = A[:, :3] - B[:, :3]
+    dr -= L * np.round(dr / L)
+    assert np.max(np.abs(dr)) < 1e-7 * L
+    assert np.max(np.abs(A[:, 3:6] - B[:, 3:6])) < 1e-6 * np.max(np.abs(A[:, 3:6]))
+    print(f"[seam B, {world} ranks] molecules per rank {per_rank}")

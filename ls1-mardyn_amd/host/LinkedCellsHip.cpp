@@ -218,22 +218,32 @@ void LinkedCellsHip::uploadFromMirror() {
 	for (int k = 0; k < 27; ++k) nbr[k] = 0;  // DomainDecompBase: every side is periodic onto this rank
 	if (_multiRank) dd->neighbourTable(glen, nbr);
 	if ((rc = ls1hip_set_domain(_ctx, glen, bmin, bmax, _multiRank ? dd->getRank() : 0, nbr))) die("ls1hip_set_domain", rc);
-	std::vector<uint64_t> id;
-	std::vector<int32_t> cid;
-	std::vector<double> r, v, q, D;
+	// streamed in chunks straight from the mirror's iterator (a full copy in six vectors next to the mirror's Molecule objects
+	// cost ~17 GB of host memory more at 10^8 molecules): the announced total is an upper bound that sizes the device arrays
 	const unsigned long n0 = _mirror.getNumberOfParticles();
-	id.reserve(n0); cid.reserve(n0); r.reserve(3 * n0); v.reserve(3 * n0); q.reserve(4 * n0); D.reserve(3 * n0);
+	constexpr size_t CHUNK = 1u << 20;
+	std::vector<uint64_t> id(CHUNK);
+	std::vector<int32_t> cid(CHUNK);
+	std::vector<double> r(3 * CHUNK), v(3 * CHUNK), q(4 * CHUNK), D(3 * CHUNK);
+	if ((rc = ls1hip_upload_begin(_ctx, n0))) die("ls1hip_upload_begin", rc);
+	size_t k = 0;
+	auto flush = [&]() {
+		if (k && (rc = ls1hip_upload_chunk(_ctx, k, id.data(), cid.data(), r.data(), v.data(), q.data(), D.data()))) die("ls1hip_upload_chunk", rc);
+		k = 0;
+	};
 	for (auto m = _mirror.iterator(ParticleIterator::ONLY_INNER_AND_BOUNDARY); m.isValid(); ++m) {
-		id.push_back(m->getID());
-		cid.push_back((int32_t)m->componentid());
+		id[k] = m->getID();
+		cid[k] = (int32_t)m->componentid();
 		for (int d = 0; d < 3; ++d) {
-			r.push_back(m->r(d));
-			v.push_back(m->v(d));
-			D.push_back(m->D(d));
+			r[3 * k + d] = m->r(d);
+			v[3 * k + d] = m->v(d);
+			D[3 * k + d] = m->D(d);
 		}
-		q.push_back(m->q().qw()); q.push_back(m->q().qx()); q.push_back(m->q().qy()); q.push_back(m->q().qz());
+		q[4 * k] = m->q().qw(); q[4 * k + 1] = m->q().qx(); q[4 * k + 2] = m->q().qy(); q[4 * k + 3] = m->q().qz();
+		if (++k == CHUNK) flush();
 	}
-	if ((rc = ls1hip_upload(_ctx, id.size(), id.data(), cid.data(), r.data(), v.data(), q.data(), D.data()))) die("ls1hip_upload", rc);
+	flush();
+	if ((rc = ls1hip_upload_end(_ctx))) die("ls1hip_upload_end", rc);
 	_uploaded = true;
 	_hostDirty = false;
 }

@@ -436,7 +436,7 @@ def test_seam_a_soa_forces_matches_reference():
 
 
 # ---- the LDS-tiled single-centre LJ kernel (kernels_force_lj.hip) ------------------------------------------------
-LJ1_CASES = ["U0", "F0", "U0_periodic", "lj1clj", "bcc1clj_3456", "bcc1clj_16000"]
+LJ1_CASES = ["U0", "F0", "U0_periodic", "lj1clj", "bcc1clj_3456", "bcc1clj_16000", "bcc1clj_8192"]
 
 
 @pytest.mark.parametrize("split", [0, 1, 2, 4, 5, 6])

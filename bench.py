@@ -141,7 +141,10 @@ def _run_reference(binary, cfg_text, steps, cores, budget_s, extra_files=None):
         except subprocess.TimeoutExpired:
             return None, None
         m = re.search(r"Simulation speed:\s*([0-9.eE+-]+)\s*Molecule-updates per second", out)
-        nm = re.search(r"[Nn]umber of molecules[^0-9]*([0-9]+)", out)
+        nm = re.search(r"System initialised with\s*([0-9]+)\s*molecules", out) or re.search(r"[Nn]umber of molecules[^0-9]*([0-9]+)", out)
+        ran = len(re.findall(r"Simstep = \d+", out)) - 1  # (the line of the initial state is not a step)
+        if ran < steps:
+            return None, None  # the driver did not run the requested steps: no baseline rather than a wrong one
         return (float(m.group(1)) if m else None), (nm.group(1) if nm else None)
 
 
@@ -267,8 +270,9 @@ def replicate_phase_space(inp, ps, k):
     r = (ps.r[None, :, :] + shifts[:, None, :]).reshape(-1, 3)
     t = lambda a: np.tile(a, (k ** 3,) + (1,) * (a.ndim - 1))  # noqa: E731
     q = ps.q / np.linalg.norm(ps.q, axis=1, keepdims=True)
+    # time 0: the reference starts counting steps at round(time / dt) and --steps is an absolute step number (Simulation.cpp:911,1375)
     return inp.PhaseSpace(ps.components, ps.length * k, np.arange(1, n0 * k ** 3 + 1, dtype=np.uint64), t(ps.cid), r, t(ps.v), t(q),
-                          t(ps.D), ps.time, ps.temperature)
+                          t(ps.D), 0.0, ps.temperature)
 
 
 def mixed_box(inp, n):
@@ -431,7 +435,7 @@ def main():
         if args.gpus != 1 or args.decomp:
             sys.exit("bench.py --workload ethane|mixed runs on one GPU (multi-site lists serve single-rank domains)")
         if args.skin == 0.2:  # the default is in sigma of the LJ liquid; multi-site boxes are in atomic units
-            args.skin = {"ethane": 5.0, "mixed": 3.0}[args.workload]
+            args.skin = {"ethane": 4.0, "mixed": 3.0}[args.workload]  # (sweep: profiles/r3_ms_skin_sweep.txt)
 
     # stdout carries ONE JSON line: libraries that print to file descriptor 1 (RCCL prints a version banner when the first
     # communicator is created) are sent to stderr for the duration of the run; the result goes to the saved descriptor

@@ -259,8 +259,10 @@ __global__ void __launch_bounds__(256) k_msl_pack(ForceParams P, double* __restr
 }
 
 // ---- REUSE: forces from the pair stream, one wave per group ----------------------------------------------------------------------
-template <bool WITH_ROT>
-__global__ void __launch_bounds__(64) k_force_ms_list(ForceParams P, const uint32_t* __restrict__ off, const uint32_t* __restrict__ pj,
+// LJ_ONLY: no electrostatic sites in the component set — the multipole bodies are compiled out, the kernel needs half the
+// registers (four waves per SIMD instead of two: the gathers of a latency-bound pair stream want the occupancy)
+template <bool WITH_ROT, bool LJ_ONLY>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_force_ms_list(ForceParams P, const uint32_t* __restrict__ off, const uint32_t* __restrict__ pj,
 													  const uint8_t* __restrict__ pil, const double* __restrict__ shift27,
 													  const double* __restrict__ pk, const CompTable* __restrict__ ctab) {
 	__shared__ double sr[3][MSG];
@@ -382,7 +384,7 @@ __global__ void __launch_bounds__(64) k_force_ms_list(ForceParams P, const uint3
 				// the compiler substitutes the lane's own key — it knows tkey == t here — and every table load behind it becomes a
 				// per-lane vector load with its own latency chain)
 				const int ci_u = __builtin_amdgcn_readfirstlane(tkey) / MAXC, cj_u = __builtin_amdgcn_readfirstlane(tkey) % MAXC;
-				mol_pair<false>(ct, ci_u, ri, Ri, cj_u, rj, Rj, drm, dd < rclj2, 0.5, a);
+				mol_pair<false, ConstCompTable, LJ_ONLY>(ct, ci_u, ri, Ri, cj_u, rj, Rj, drm, dd < rclj2, 0.5, a);
 			}
 			todo &= ~__ballot(mine);
 		}
@@ -441,15 +443,17 @@ void launch_msl_fill(const ForceParams& p, const uint32_t* off, const uint32_t* 
 	hipLaunchKernelGGL(k_msl_fill, dim3(ng), dim3(MSG), 0, s, p, off, hsrc, hdir, out_j, out_il, ncomp, scratch, mcnt, stride);
 }
 
-bool launch_force_ms_list(const ForceParams& p, bool has_rot, int ncomp, const uint32_t* off, const uint32_t* pj, const uint8_t* pil,
+bool launch_force_ms_list(const ForceParams& p, bool has_rot, bool lj_only, int ncomp, const uint32_t* off, const uint32_t* pj, const uint8_t* pil,
 						  const double* shift27, double* pk, hipStream_t s, uint32_t* nblocks, size_t partials_cap) {
 	const uint32_t ng = msl_groups(p.n_real_cap);
 	if ((size_t)ng > partials_cap || p.which != 0) return false;
 	*nblocks = ng;
 	if (ng == 0) return true;
 	hipLaunchKernelGGL(k_msl_pack, dim3((p.n_real_cap + 255u) / 256u), dim3(256), 0, s, p, pk, has_rot ? 1 : 0, ncomp);
-	if (has_rot) hipLaunchKernelGGL((k_force_ms_list<true>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);
-	else hipLaunchKernelGGL((k_force_ms_list<false>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);
+	if (has_rot && lj_only) hipLaunchKernelGGL((k_force_ms_list<true, true>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);
+	else if (has_rot) hipLaunchKernelGGL((k_force_ms_list<true, false>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);
+	else if (lj_only) hipLaunchKernelGGL((k_force_ms_list<false, true>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);
+	else hipLaunchKernelGGL((k_force_ms_list<false, false>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);
 	return true;
 }
 

@@ -41,7 +41,8 @@ LS1_HD V3 ld3(const T3& t, int k) {  // t: double [n][3] in any address space
 // w = weight of the pair's macroscopic contribution seen from i (0.5 in full-shell mode).
 // CT: CompTable in any address space (kernels_force_mslist.hip reads it through the constant address space, so that the
 // table loads behind its wave-uniform component indices become scalar loads)
-template <bool WITH_VI, class CT = CompTable>
+// LJ_ONLY: the component set has no charges, dipoles or quadrupoles (their loops — and their registers — are compiled out)
+template <bool WITH_VI, class CT = CompTable, bool LJ_ONLY = false>
 LS1_HD void mol_pair(const CT& ct, int ci, V3 ri, const Rot& Ri, int cj, V3 rj, const Rot& Rj, V3 drm,
 					 bool calcLJ, double w, MolAcc& a) {
 	V3 Fp = {0., 0., 0.};  // force on i from this pair (for the virial)
@@ -49,9 +50,9 @@ LS1_HD void mol_pair(const CT& ct, int ci, V3 ri, const Rot& Ri, int cj, V3 rj, 
 	V3 f, m1, m2;
 	double u;
 	const int nlji = ct.nlj[ci], nljj = ct.nlj[cj];
-	const int nci = ct.nc[ci], ncj = ct.nc[cj];
-	const int ndi = ct.nd[ci], ndj = ct.nd[cj];
-	const int nqi = ct.nq[ci], nqj = ct.nq[cj];
+	const int nci = LJ_ONLY ? 0 : ct.nc[ci], ncj = LJ_ONLY ? 0 : ct.nc[cj];
+	const int ndi = LJ_ONLY ? 0 : ct.nd[ci], ndj = LJ_ONLY ? 0 : ct.nd[cj];
+	const int nqi = LJ_ONLY ? 0 : ct.nq[ci], nqj = LJ_ONLY ? 0 : ct.nq[cj];
 	if (calcLJ) {
 		for (int si = 0; si < nlji; ++si) {
 			const int gi = ct.olj[ci] + si;

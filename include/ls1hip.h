@@ -207,6 +207,10 @@ int ls1hip_forces(ls1hip_ctx* ctx, int which, double* upot, double* virial);
 int ls1hip_kick(ls1hip_ctx* ctx, double dt_half, double* summv2, double* sumIw2, uint64_t* n, uint64_t* rot_dof);
 /* The kinetic sums of the last ls1hip_kick, for callers that queued it with NULL outputs (asynchronously) and fetch later. */
 int ls1hip_kinetic_sums(ls1hip_ctx* ctx, double* summv2, double* sumIw2, uint64_t* n, uint64_t* rot_dof);
+/* Component-wise thermostats (Domain::severalThermostats()): the sums of Leapfrog::transition2to3 (integrators/Leapfrog.cpp:84-104)
+ * per COMPONENT — arrays of ncomp entries: sum m v^2, sum I w^2, N, rotational DOF of the component's owned molecules, from the
+ * current velocities (call after ls1hip_kick).  The caller folds components into thermostats (Domain::getThermostat). */
+int ls1hip_kinetic_sums_by_component(ls1hip_ctx* ctx, int ncomp, double* summv2, double* sumIw2, uint64_t* n, uint64_t* rot_dof);
 /* Overlap of host and device work around a traversal: ls1hip_forces / ls1hip_forces_list with upot = virial = NULL only queue
  * the kernels.  ls1hip_traversal_mark queues a copy of the traversal's sums behind them; ls1hip_traversal_sums waits for THAT
  * copy only — whatever was queued after the mark (typically the post-force ls1hip_kick with NULL outputs) keeps running on
@@ -229,6 +233,10 @@ int ls1hip_forces_kick_drift(ls1hip_ctx* ctx, int which, double dt, double* upot
  * :48-64) in ONE pass over the molecules: v += dt/m F; r += dt v (and the rotational counterparts) — bitwise the same
  * as ls1hip_kick(dt/2) + ls1hip_kick_drift(dt), for steps whose kinetic sums are not needed (NVE, no output). */
 int ls1hip_kick_then_kick_drift(ls1hip_ctx* ctx, double dt);
+/* ls1hip_scale_kick_drift with one factor pair per COMPONENT: VelocityScalingThermostat::apply, componentwise branch
+ * (thermostats/VelocityScalingThermostat.cpp:45-69; the driver sets the factors of a component's thermostat,
+ * Simulation.cpp:1111-1127), folded into the pre-force kick + drift pass. */
+int ls1hip_scale_kick_drift_components(ls1hip_ctx* ctx, int ncomp, const double* beta_trans, const double* beta_rot, double dt);
 
 /* VelocityScalingThermostat::apply, global branch (thermostats/VelocityScalingThermostat.cpp:80-96): v *= beta_trans,
  * D *= beta_rot for every owned molecule. */

@@ -46,6 +46,8 @@ SYMBOLS = {
     "ls1hip_download_forces": (C.c_int, [C.c_void_p, C.c_size_t, _dp, _dp, _dp]),
     "ls1hip_kick_drift": (C.c_int, [C.c_void_p, C.c_double]),
     "ls1hip_scale_kick_drift": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
+    "ls1hip_scale_kick_drift_components": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, C.c_double]),
+    "ls1hip_kinetic_sums_by_component": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _u64p, _u64p]),
     "ls1hip_kinetic_sums": (C.c_int, [C.c_void_p, _dp, _dp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ls1hip_traversal_mark": (C.c_int, [C.c_void_p]),
     "ls1hip_traversal_sums": (C.c_int, [C.c_void_p, _dp, _dp]),

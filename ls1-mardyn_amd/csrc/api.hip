@@ -1237,6 +1237,62 @@ extern "C" int ls1hip_kick(ls1hip_ctx* c, double dt_half, double* summv2, double
 	return LS1HIP_OK;
 }
 
+// Component-wise thermostats (Domain::severalThermostats): the kinetic sums of Leapfrog::transition2to3 (Leapfrog.cpp:84-104) per
+// COMPONENT, from the current velocities / angular momenta (i.e. after ls1hip_kick); the caller folds components into thermostats
+// (Domain::getThermostat).  A separate pass over v, D, q, cid (only taken by runs with several thermostats).
+extern "C" int ls1hip_kinetic_sums_by_component(ls1hip_ctx* c, int ncomp, double* summv2, double* sumIw2, uint64_t* n, uint64_t* rot_dof) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, c->have_comp && ncomp == c->h_ct.ncomp, "ncomp must be the number of components (%d)", c->h_ct.ncomp);
+	REQUIRE(c, c->cap_real, "no molecules uploaded");
+	HIPCHK(c, hipSetDevice(c->device));
+	{
+		TimedScope ts(c, c->t_integrate);
+		launch_kin_by_component(integ_args(c, 0.), ncomp, c->d_partials, c->d_stage, c->stream);
+		HIPCHK(c, hipGetLastError());
+	}
+	double h[MAXC * 4];
+	HIPCHK(c, hipMemcpyAsync(h, c->d_stage, (size_t)ncomp * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	for (int k = 0; k < ncomp; ++k) {
+		if (summv2) summv2[k] = h[4 * k];
+		if (sumIw2) sumIw2[k] = h[4 * k + 1];
+		if (n) n[k] = (uint64_t)(h[4 * k + 2] + 0.5);
+		if (rot_dof) rot_dof[k] = (uint64_t)(h[4 * k + 3] + 0.5);
+	}
+	return LS1HIP_OK;
+}
+
+// VelocityScalingThermostat::apply, componentwise branch (thermostats/VelocityScalingThermostat.cpp:45-69: v *= beta_trans, D *=
+// beta_rot of the molecule's thermostat) folded into the pre-force kick + drift, with one factor pair per component
+extern "C" int ls1hip_scale_kick_drift_components(ls1hip_ctx* c, int ncomp, const double* beta_trans, const double* beta_rot, double dt) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, c->have_comp && ncomp == c->h_ct.ncomp && beta_trans && beta_rot, "one (beta_trans, beta_rot) pair per component (%d)", c->h_ct.ncomp);
+	REQUIRE(c, c->cap_real, "no molecules uploaded");
+	REQUIRE(c, !c->fused_split, "a fused inner pass is waiting for its boundary pass");
+	HIPCHK(c, hipSetDevice(c->device));
+	if (c->pos_x && !c->vl_ready) {
+		int rcm = materialise_positions(c);
+		if (rcm) return rcm;
+	}
+	TimedScope ts(c, c->t_integrate);
+	IntegArgs a = c->vl_ready ? integ_args_lists(c, dt) : integ_args(c, dt);
+	a.pre_scale = 3;
+	for (int k = 0; k < MAXC; ++k) {
+		a.pre_bt_c[k] = k < ncomp ? beta_trans[k] : 1.;
+		a.pre_br_c[k] = k < ncomp ? beta_rot[k] : 1.;
+	}
+	launch_kick_drift(a, c->stream);
+	if (c->vl_ready) {
+		int rcb = track_unfused_drift(c, dt);
+		if (rcb) return rcb;
+	}
+	HIPCHK(c, hipGetLastError());
+	c->binned = false;
+	c->halo_valid = false;
+	c->forces_valid = false;
+	return LS1HIP_OK;
+}
+
 extern "C" int ls1hip_kinetic_sums(ls1hip_ctx* c, double* summv2, double* sumIw2, uint64_t* n, uint64_t* rot_dof) {
 	if (!c) return LS1HIP_EINVAL;
 	HIPCHK(c, hipSetDevice(c->device));

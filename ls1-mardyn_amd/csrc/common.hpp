@@ -393,9 +393,14 @@ struct IntegArgs {
 	double* vmax_part;  // list mode: per-workgroup max |v_drift|^2 of a kick + drift pass (null otherwise)
 	// kick + drift passes: velocity scaling of the thermostat applied to v / D as they are read (same arithmetic as a separate
 	// k_scale pass before: v * beta, then the kick), 0 = off, 1 = factors below, 2 = factors from cnt->beta
+	// 3 = per-component factors (component-wise thermostats: VelocityScalingThermostat::apply, componentwise branch)
 	int pre_scale = 0;
 	double pre_bt = 1., pre_br = 1.;
+	double pre_bt_c[MAXC], pre_br_c[MAXC];
 };
+// kinetic sums per COMPONENT of the current velocities / angular momenta: out[c][4] = {sum m v^2, sum I w^2, N, rotational DOF}
+// (the host folds components into thermostats: Leapfrog.cpp:84-104, Domain::getThermostat)
+void launch_kin_by_component(const IntegArgs& a, int ncomp, double* scratch, double* out, hipStream_t s);
 void launch_bound_update(DevCounters* cnt, const double* vmax_part, uint32_t nblocks, double dt, double limit, bool fresh, uint32_t seq,
 						 volatile uint32_t* flag, hipStream_t s);
 void launch_kick_drift(const IntegArgs& a, hipStream_t s);

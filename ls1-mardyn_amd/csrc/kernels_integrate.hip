@@ -40,8 +40,8 @@ __global__ void __launch_bounds__(ITPB) k_kick_drift(IntegArgs a) {
 	const double dtInv2m = dt_halve / a.ct->mass[c];
 	double bt = 1., br = 1.;
 	if (a.pre_scale) {  // VelocityScalingThermostat::apply folded into this pass (uniform branch)
-		bt = a.pre_scale == 2 ? a.cnt->beta[0] : a.pre_bt;
-		br = a.pre_scale == 2 ? a.cnt->beta[1] : a.pre_br;
+		bt = a.pre_scale == 2 ? a.cnt->beta[0] : a.pre_scale == 3 ? a.pre_bt_c[c] : a.pre_bt;
+		br = a.pre_scale == 2 ? a.cnt->beta[1] : a.pre_scale == 3 ? a.pre_br_c[c] : a.pre_br;
 	}
 	double vx = a.mol.vx[p], vy = a.mol.vy[p], vz = a.mol.vz[p];
 	if (a.pre_scale) {
@@ -205,6 +205,71 @@ __global__ void __launch_bounds__(ITPB) k_kick(IntegArgs a) {
 		for (int i = 0; i < ITPB / 64; ++i) s += red[i][threadIdx.x];
 		a.partials[(size_t)blockIdx.x * 4 + threadIdx.x] = s;
 	}
+}
+
+// ---- kinetic sums per component (component-wise thermostats) -----------------------------------------------------------------------
+template <bool HAS_ROT>
+__global__ void __launch_bounds__(ITPB) k_kin_by_component(IntegArgs a, int ncomp, double* __restrict__ part) {
+	const uint32_t p = blockIdx.x * ITPB + threadIdx.x;
+	double mv2 = 0., Iw2 = 0., rdof = 0., one = 0.;
+	int c = -1;
+	if (p < a.cnt->n_real) {
+		c = ncomp > 1 ? a.mol.cid[p] : 0;
+		const double m = a.ct->mass[c];
+		const double vx = a.mol.vx[p], vy = a.mol.vy[p], vz = a.mol.vz[p];
+		mv2 = m * (vx * vx + vy * vy + vz * vz);
+		rdof = (double)a.ct->rotdof[c];
+		one = 1.;
+		if (HAS_ROT) {
+			const V3 D = {a.mol.Dx[p], a.mol.Dy[p], a.mol.Dz[p]};
+			V3 w = rotate_inv(rot_of(a.mol.q0[p], a.mol.q1[p], a.mol.q2[p], a.mol.q3[p]), D);
+			w = {w.x * a.ct->invI[c][0], w.y * a.ct->invI[c][1], w.z * a.ct->invI[c][2]};
+			Iw2 = a.ct->I[c][0] * w.x * w.x + a.ct->I[c][1] * w.y * w.y + a.ct->I[c][2] * w.z * w.z;
+		}
+	}
+	__shared__ double red[ITPB / 64][MAXC][4];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	for (int k = 0; k < ncomp; ++k) {  // fixed order of the sums: deterministic
+		const bool mine = c == k;
+		const double s0 = wave_sum_i(mine ? mv2 : 0.), s1 = wave_sum_i(mine ? Iw2 : 0.), s2 = wave_sum_i(mine ? one : 0.),
+					 s3 = wave_sum_i(mine ? rdof : 0.);
+		if (lane == 0) {
+			red[wv][k][0] = s0;
+			red[wv][k][1] = s1;
+			red[wv][k][2] = s2;
+			red[wv][k][3] = s3;
+		}
+	}
+	__syncthreads();
+	if ((int)threadIdx.x < ncomp * 4) {
+		const int k = threadIdx.x >> 2, q = threadIdx.x & 3;
+		double sum = 0.;
+		for (int i = 0; i < ITPB / 64; ++i) sum += red[i][k][q];
+		part[((size_t)blockIdx.x * MAXC + k) * 4 + q] = sum;
+	}
+}
+__global__ void __launch_bounds__(256) k_kin_by_component_reduce(const double* __restrict__ part, uint32_t nb, int ncomp, double* __restrict__ out) {
+	__shared__ double red[4];
+	for (int kq = 0; kq < ncomp * 4; ++kq) {
+		const int k = kq >> 2, q = kq & 3;
+		double v = 0.;
+		for (uint32_t b = threadIdx.x; b < nb; b += 256) v += part[((size_t)b * MAXC + k) * 4 + q];
+		v = wave_sum_i(v);
+		if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+		__syncthreads();
+		if (threadIdx.x == 0) out[kq] = red[0] + red[1] + red[2] + red[3];
+		__syncthreads();
+	}
+}
+void launch_kin_by_component(const IntegArgs& a, int ncomp, double* scratch, double* out, hipStream_t s) {
+	const uint32_t nb = (a.n_cap + ITPB - 1) / ITPB;
+	if (nb == 0) {
+		hipMemsetAsync(out, 0, (size_t)ncomp * 4 * sizeof(double), s);
+		return;
+	}
+	if (a.has_rot) hipLaunchKernelGGL(k_kin_by_component<true>, dim3(nb), dim3(ITPB), 0, s, a, ncomp, scratch);
+	else hipLaunchKernelGGL(k_kin_by_component<false>, dim3(nb), dim3(ITPB), 0, s, a, ncomp, scratch);
+	hipLaunchKernelGGL(k_kin_by_component_reduce, dim3(1), dim3(256), 0, s, scratch, nb, ncomp, out);
 }
 
 void launch_kick_drift(const IntegArgs& a, hipStream_t s) {

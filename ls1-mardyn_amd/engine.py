@@ -231,6 +231,17 @@ class DeviceEngine:
         self._chk(self.lib.ls1hip_kick(self.ctx, float(dt_half), C.byref(a), C.byref(b), C.byref(n), C.byref(rd)))
         return a.value, b.value, n.value, rd.value
 
+    def kinetic_sums_by_component(self, ncomp: int):
+        """{summv2, sumIw2, n, rot_dof} arrays per component (component-wise thermostats)"""
+        a = np.zeros(ncomp); b = np.zeros(ncomp); n = np.zeros(ncomp, np.uint64); rd = np.zeros(ncomp, np.uint64)
+        self._chk(self.lib.ls1hip_kinetic_sums_by_component(self.ctx, int(ncomp), capi.dptr(a), capi.dptr(b),
+                                                            n.ctypes.data_as(capi._u64p), rd.ctypes.data_as(capi._u64p)))
+        return dict(summv2=a, sumIw2=b, n=n, rot_dof=rd)
+
+    def scale_kick_drift_components(self, beta_trans, beta_rot, dt):
+        bt = np.ascontiguousarray(beta_trans, dtype=np.float64); br = np.ascontiguousarray(beta_rot, dtype=np.float64)
+        self._chk(self.lib.ls1hip_scale_kick_drift_components(self.ctx, len(bt), capi.dptr(bt), capi.dptr(br), float(dt)))
+
     def scale_velocities(self, beta_trans, beta_rot=1.0):
         self._chk(self.lib.ls1hip_scale_velocities(self.ctx, float(beta_trans), float(beta_rot)))
 

@@ -19,6 +19,7 @@
 #include "LinkedCellsHip.h"
 
 #include <cstdlib>
+#include <map>
 
 #include "Domain.h"
 #include "Simulation.h"
@@ -351,11 +352,15 @@ void LinkedCellsHip::deviceAdvanced() {
 
 void LinkedCellsHip::syncMirrorFromDevice(bool applyPendingBeta) {
 	if (!_uploaded) return;
-	double betaTrans = 1., betaRot = 1.;
-	if (applyPendingBeta) {  // global thermostat only (component-wise ones are rejected by the integrator)
+	std::vector<Component>& comps0 = *(global_simulation->getEnsemble()->getComponents());
+	std::vector<double> betaT(comps0.size(), 1.), betaR(comps0.size(), 1.);
+	if (applyPendingBeta) {  // the factors the next eventNewTimestep will apply on the device (global or per thermostat)
 		Domain* domain = global_simulation->getDomain();
-		betaTrans = domain->getGlobalBetaTrans();
-		betaRot = domain->getGlobalBetaRot();
+		for (size_t k = 0; k < comps0.size(); ++k) {
+			const bool several = domain->severalThermostats();
+			betaT[k] = several ? domain->getGlobalBetaTrans(domain->getThermostat((int)k)) : domain->getGlobalBetaTrans();
+			betaR[k] = several ? domain->getGlobalBetaRot(domain->getThermostat((int)k)) : domain->getGlobalBetaRot();
+		}
 	}
 	size_t n = 0, h = 0;
 	ls1hip_count(_ctx, &n, &h);
@@ -370,6 +375,7 @@ void LinkedCellsHip::syncMirrorFromDevice(bool applyPendingBeta) {
 	std::vector<Molecule> mols;
 	mols.reserve(n);
 	for (size_t i = 0; i < n; ++i) {
+		const double betaTrans = betaT[cid[i]], betaRot = betaR[cid[i]];
 		Molecule m(id[i], &comps[cid[i]], r[3 * i], r[3 * i + 1], r[3 * i + 2], betaTrans * v[3 * i], betaTrans * v[3 * i + 1],
 				   betaTrans * v[3 * i + 2], q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3], betaRot * D[3 * i],
 				   betaRot * D[3 * i + 1], betaRot * D[3 * i + 2]);
@@ -412,10 +418,25 @@ void LeapfrogHip::eventNewTimestep(ParticleContainer* moleculeContainer, Domain*
 		// VelocityScalingThermostat::apply of the step just finished (Simulation.cpp:1108-1131), global thermostat — folded into
 		// the same pass over the molecules as transition3to1 + transition1to2 (FullMolecule::upd_preF, Leapfrog.cpp:48-64)
 		if (domain->severalThermostats()) {
-			global_log->error() << "LeapfrogHip: component-wise thermostats are not available on the device path" << std::endl;
-			Simulation::exit(685);
-		}
-		if ((rc = ls1hip_scale_kick_drift(ctx, domain->getGlobalBetaTrans(), domain->getGlobalBetaRot(), _timestepLength))) {
+			// componentwise branch of VelocityScalingThermostat::apply (VelocityScalingThermostat.cpp:45-69) with the factors the
+			// driver hands it (Simulation.cpp:1111-1127): one pair per component = that of the component's thermostat
+			std::vector<Component>& comps = *(global_simulation->getEnsemble()->getComponents());
+			std::vector<double> bt(comps.size(), 1.), br(comps.size(), 1.);
+			for (size_t cid = 0; cid < comps.size(); ++cid) {
+				const int th = domain->getThermostat((int)cid);
+				for (int d = 0; d < 3; ++d)
+					if (domain->getThermostatDirectedVelocity(th, d) != 0.) {
+						global_log->error() << "LeapfrogHip: thermostats with a directed velocity are not available on the device path" << std::endl;
+						Simulation::exit(685);
+					}
+				bt[cid] = domain->getGlobalBetaTrans(th);
+				br[cid] = domain->getGlobalBetaRot(th);
+			}
+			if ((rc = ls1hip_scale_kick_drift_components(ctx, (int)comps.size(), bt.data(), br.data(), _timestepLength))) {
+				global_log->error() << "ls1hip_scale_kick_drift_components: " << ls1hip_last_error(ctx) << std::endl;
+				Simulation::exit(686);
+			}
+		} else if ((rc = ls1hip_scale_kick_drift(ctx, domain->getGlobalBetaTrans(), domain->getGlobalBetaRot(), _timestepLength))) {
 			global_log->error() << "ls1hip_scale_kick_drift: " << ls1hip_last_error(ctx) << std::endl;
 			Simulation::exit(686);
 		}
@@ -442,9 +463,37 @@ void LeapfrogHip::eventForcesCalculated(ParticleContainer* moleculeContainer, Do
 		global_log->error() << "ls1hip_kick: " << ls1hip_last_error(ctx) << std::endl;
 		Simulation::exit(688);
 	}
-	domain->setLocalSummv2(summv2, 0);
-	domain->setLocalSumIw2(sumIw2, 0);
-	domain->setLocalNrotDOF(0, n, rotdof);
+	if (domain->severalThermostats()) {
+		// Leapfrog::transition2to3, several thermostats (Leapfrog.cpp:84-104, 142-146): sums keyed by the thermostat of the
+		// molecule's component; thermostat 0 (the whole system) is formed by Domain::calculateGlobalValues from the others
+		std::vector<Component>& comps = *(global_simulation->getEnsemble()->getComponents());
+		const int nc = (int)comps.size();
+		std::vector<double> mv2(nc), iw2(nc);
+		std::vector<uint64_t> nn(nc), rd(nc);
+		if ((rc = ls1hip_kinetic_sums_by_component(ctx, nc, mv2.data(), iw2.data(), nn.data(), rd.data()))) {
+			global_log->error() << "ls1hip_kinetic_sums_by_component: " << ls1hip_last_error(ctx) << std::endl;
+			Simulation::exit(688);
+		}
+		std::map<int, double> tmv2, tiw2;
+		std::map<int, unsigned long> tn, trd;
+		for (int cid = 0; cid < nc; ++cid) {
+			if (nn[cid] == 0) continue;  // (the reference's maps only hold thermostats that own molecules on this rank)
+			const int th = domain->getThermostat(cid);
+			tmv2[th] += mv2[cid];
+			tiw2[th] += iw2[cid];
+			tn[th] += nn[cid];
+			trd[th] += rd[cid];
+		}
+		for (auto& it : tmv2) {
+			domain->setLocalSummv2(it.second, it.first);
+			domain->setLocalSumIw2(tiw2[it.first], it.first);
+			domain->setLocalNrotDOF(it.first, tn[it.first], trd[it.first]);
+		}
+	} else {
+		domain->setLocalSummv2(summv2, 0);
+		domain->setLocalSumIw2(sumIw2, 0);
+		domain->setLocalNrotDOF(0, n, rotdof);
+	}
 	_haveBeta = true;
 	_state = STATE_POST_FORCE_CALCULATION;
 	++_stepsDone;

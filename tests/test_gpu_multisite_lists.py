@@ -230,3 +230,62 @@ def test_config3_ethane_10m_replicated_through_the_list_pass():
     small = dict(F=g["recs"]["F"], M=g["recs"]["M"], Vi=np.zeros((n0, 3)), upot=g["upot"], virial=g["virial"])
     check_replicas(big, small, n0, k, np.random.default_rng(5))
     e.close()
+
+
+def test_component_wise_thermostat_entry_points():
+    """Several thermostats (Domain::severalThermostats; integrators/Leapfrog.cpp:84-104, thermostats/VelocityScalingThermostat.cpp:45-69):
+    ls1hip_kinetic_sums_by_component == the sums of the downloaded state per component (sum m v^2, sum I w^2 through rotateinv and
+    I^-1 as FullMolecule::upd_postF, N, rotational DOF), and ls1hip_scale_kick_drift_components == scaling every molecule by its
+    component's factors followed by ls1hip_kick_drift (bitwise: same arithmetic, one pass).  (The XML driver of this reference version
+    cannot assign thermostats to components — Simulation.cpp:484-487 always finds thermostat 0 — so the LeapfrogHip branch that
+    calls these is exercised here, at the C ABI.)"""
+    comps, length, rc, ids, cid, r, v, q, D = _mixture_in_the_ethane_box()
+    rng = np.random.default_rng(4)
+    D = rng.normal(0, 0.01, r.shape)
+    ncomp = len(comps.components)
+    res = []
+    for fused in (True, False):
+        e = engine_mod.DeviceEngine(0)
+        e.set_components(comps, rc)
+        e.set_domain(length)
+        e.upload(ids, cid, r, v, q, D)
+        e.rebin(); e.halo(); e.forces(0)
+        e.kick(0.25)
+        if fused:
+            s = e.kinetic_sums_by_component(ncomp)
+            st = e.download_state()
+            o = np.argsort(st["ids"], kind="stable")
+            vv, DD, qq, cc = st["v"][o], st["D"][o], st["q"][o], st["cid"][o]
+            for k, c in enumerate(comps.components):
+                m = cc == k
+                assert s["n"][k] == m.sum() and s["rot_dof"][k] == m.sum() * c.rot_dof
+                mv2 = c.mass * (vv[m] ** 2).sum()
+                assert abs(s["summv2"][k] - mv2) <= 1e-12 * mv2
+                # w = I^-1 R^T D  (Quaternion::rotateinv), sum I w^2
+                w0, x, y, z = qq[m].T
+                R = np.array([[w0*w0+x*x-y*y-z*z, 2*(x*y-w0*z), 2*(w0*y+x*z)], [2*(w0*z+x*y), w0*w0-x*x+y*y-z*z, 2*(y*z-w0*x)],
+                              [2*(x*z-w0*y), 2*(w0*x+y*z), w0*w0-x*x-y*y+z*z]])
+                Db = np.einsum("jin,nj->ni", R, DD[m])
+                Iw2 = sum((Db[:, d] ** 2 / c.I[d]).sum() for d in range(3) if c.I[d] > 0)
+                assert abs(s["sumIw2"][k] - Iw2) <= 1e-11 * max(Iw2, 1e-300) + 1e-300
+            e.scale_kick_drift_components([0.97, 1.02, 1.05], [1.01, 1.0, 0.96], 0.5)
+        else:
+            # the same by hand: scale per component on the host, then the plain kick + drift
+            st = e.download_state()
+            f = e.download_forces()
+            bt = np.array([0.97, 1.02, 1.05])[st["cid"]][:, None]
+            br = np.array([1.01, 1.0, 0.96])[st["cid"]][:, None]
+            e2 = engine_mod.DeviceEngine(0)
+            e2.set_components(comps, rc)
+            e2.set_domain(length)
+            e2.upload(st["ids"], st["cid"], st["r"], st["v"] * bt, st["q"], st["D"] * br)
+            e2.rebin(); e2.halo(); e2.forces(0)
+            e2.kick_drift(0.5)
+            e.close()
+            e = e2
+        st = e.download_state()
+        o = np.argsort(st["ids"], kind="stable")
+        res.append({k: st[k][o] for k in ("r", "v", "q", "D")})
+        e.close()
+    for k in ("r", "v", "q", "D"):
+        assert rel_max(res[0][k], res[1][k]) < 1e-13, k

@@ -119,6 +119,44 @@ __device__ __forceinline__ void v_pair(double xi, double yi, double zi, double x
 	a.vir = fma(fac, d, a.vir);
 }
 
+// Four listed pairs (one list word) with ONE reciprocal: v_rcp_f64 is a quarter-rate instruction (16 cycles against 4 for an FMA),
+// so 1 / r2 of four pairs is formed from the reciprocal of their PRODUCT: x = 1 / (a b c d) (v_rcp_f64 + one Newton step), then
+// 1 / (a b) = (c d) x, 1 / a = b / (a b), ... — nine multiplications + one reciprocal instead of four reciprocals with a Newton step
+// each: 15 issue slots instead of 24 per word (- 9 % of the pair loop's VALU time).  Out-of-range pairs get r2 := 1e75 (only the
+// high dword is replaced), so that the product of four stays finite: their terms come out as ~1e-225 instead of exactly 0 —
+// absorbed by any non-zero sum.  Relative error of 1 / r2: 2.5e-15 (one reciprocal + Newton: 2.2e-15).
+template <bool COUNT, bool SIG1 = false>
+__device__ __forceinline__ void v_pair4(double xi, double yi, double zi, const double (&xj)[4], const double (&yj)[4], const double (&zj)[4],
+										double rc2, double sig2, VAcc& a) {
+	double dx[4], dy[4], dz[4], d[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		dx[k] = xi - xj[k];
+		dy[k] = yi - yj[k];
+		dz[k] = zi - zj[k];
+		const double r2 = fma(dz[k], dz[k], fma(dy[k], dy[k], dx[k] * dx[k]));
+		const bool in = r2 < rc2;
+		d[k] = __hiloint2double(in ? __double2hiint(r2) : 0x4F810000, __double2loint(r2));  // out of range: ~1e75
+		if (COUNT) a.nin += in ? 1u : 0u;
+	}
+	const double p01 = d[0] * d[1], p23 = d[2] * d[3];
+	const double x = v_rcp(p01 * p23);
+	const double i01 = p23 * x, i23 = p01 * x;  // 1 / (d0 d1), 1 / (d2 d3)
+	const double inv[4] = {d[1] * i01, d[0] * i01, d[3] * i23, d[2] * i23};
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const double lj2 = SIG1 ? inv[k] : sig2 * inv[k];
+		const double lj6 = lj2 * lj2 * lj2;
+		const double lj12m6 = fma(lj6, lj6, -lj6);
+		const double fac = inv[k] * fma(lj6, lj6, lj12m6);
+		a.fx = fma(fac, dx[k], a.fx);
+		a.fy = fma(fac, dy[k], a.fy);
+		a.fz = fma(fac, dz[k], a.fz);
+		a.slj += lj12m6;
+		a.vir = fma(fac, d[k], a.vir);
+	}
+}
+
 #ifdef LS1_N3_MOCK
 // TIMING MOCK (results are wrong by construction): what brick-internal Newton 3 would cost.  A third of a molecule's list entries
 // disappear (pairs inside the brick are listed by one partner only), and half of the remaining ones return their force to the
@@ -285,11 +323,14 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 				v_pair<SHIFT, SIG1>(xi, yi, zi, x1, y1, z1, rc2, eps24, sig2, acc);
 				v_pair_n3<SHIFT, SIG1>(xi, yi, zi, x2, y2, z2, rc2, eps24, sig2, acc, (o2 >> 3) & 511u);
 				v_pair<SHIFT, SIG1>(xi, yi, zi, x3, y3, z3, rc2, eps24, sig2, acc);
-#else
+#elif defined(LS1_PAIR1)
 				v_pair<SHIFT, SIG1>(xi, yi, zi, x0, y0, z0, rc2, eps24, sig2, acc);
 				v_pair<SHIFT, SIG1>(xi, yi, zi, x1, y1, z1, rc2, eps24, sig2, acc);
 				v_pair<SHIFT, SIG1>(xi, yi, zi, x2, y2, z2, rc2, eps24, sig2, acc);
 				v_pair<SHIFT, SIG1>(xi, yi, zi, x3, y3, z3, rc2, eps24, sig2, acc);
+#else
+				const double xj[4] = {x0, x1, x2, x3}, yj[4] = {y0, y1, y2, y3}, zj[4] = {z0, z1, z2, z3};
+				v_pair4<SHIFT, SIG1>(xi, yi, zi, xj, yj, zj, rc2, sig2, acc);
 #endif
 			};
 #ifdef LS1_N3_MOCK

@@ -259,7 +259,26 @@ extern "C" int ls1hip_get_option(const ls1hip_ctx* c, const char* name, long* v)
 			*v = (long)k;
 		}
 	}
-	else if (n == "precision_in_use") *v = (c->opt_precision && c->vl_ready && c->vl_all_regular) ? c->opt_precision : 0;
+	else if (n == "verlet_mean_words_x1000") {
+		// diagnostics: mean number of list words (4 entries each) a tile of the last single-centre list build walks = its longest
+		// list, over the tiles that hold molecules; x 1000
+		*v = 0;
+		if (c->vl_ready && c->one_clj && c->d_vl_nw && c->vl_tiles_cap) {
+			std::vector<uint8_t> h(c->vl_tiles_cap);
+			if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
+				hipMemcpy(h.data(), c->d_vl_nw, h.size(), hipMemcpyDeviceToHost) != hipSuccess)
+				return LS1HIP_EHIP;
+			// tiles 0..7 of every brick always hold molecules in a liquid; tile 8 a few, tile 9 none: count tiles 0..7 only
+			double sum = 0.;
+			size_t cnt = 0;
+			for (size_t t = 0; t < h.size(); ++t)
+				if (t % 10 < 8 && h[t] != 0xff && h[t] != 0) {
+					sum += h[t];
+					++cnt;
+				}
+			*v = cnt ? (long)(1000. * sum / (double)cnt) : 0;
+		}
+	} else if (n == "precision_in_use") *v = (c->opt_precision && c->vl_ready && c->vl_all_regular) ? c->opt_precision : 0;
 	else if (n == "can_fuse_integration") *v = can_fuse(c) ? 1 : 0;
 	else if (n == "last_force_kernel") *v = c->last_force_kernel;
 	else if (n == "verlet_lists") *v = c->vl_on ? 1 : 0;

@@ -75,6 +75,27 @@ if fk:
         fs["fp64_flop_per_launch"] = 64.0 * (2.0 * k.get("SQ_INSTS_VALU_FMA_F64", 0.0) + k.get("SQ_INSTS_VALU_ADD_F64", 0.0) +
                                              k.get("SQ_INSTS_VALU_MUL_F64", 0.0))
     summary["force_kernel"] = fs
+# The --stats average covers EVERY launch of the run (melt + warm-up + timed + profiling steps); bench.py's roofline.avg_launch_ms
+# covers the TIMED window only.  From the per-dispatch kernel trace: the dominant force kernel's launches of exactly that window
+# (one list force launch per step; launches [melt + warmup, melt + warmup + steps) of that kernel).
+trace = glob.glob(os.path.join(out, "stats", "*", "*kernel_trace.csv"))
+if trace and fk:
+    rows = [r for r in csv.DictReader(open(trace[0])) if r["Kernel_Name"].split("(")[0].replace("void ", "") == fk[0]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    cfgb = bench.get("config", {}).get("untimed_steps_before_the_timed_window", {})
+    first = int(cfgb.get("melt", 0)) + int(cfgb.get("warmup", bench.get("warmup", 0)))
+    win = rows[first:first + int(bench["steps"])]
+    if win:
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in win]
+        alld = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
+        summary["force_kernel_timed_window"] = {
+            "kernel": fk[0], "launches_in_trace": len(rows), "window": [first, first + len(win)],
+            "mean_ms_timed_window": sum(d) / len(d), "min_ms": min(d), "max_ms": max(d),
+            "mean_ms_all_launches": sum(alld) / len(alld),
+            "bench_avg_launch_ms_hip_events_same_run": bench["roofline"]["avg_launch_ms"],
+            "note": "the --stats CSV averages all launches incl. the melting lattice (shorter lists); the timed window is the one bench.py reports"}
+        with open(os.path.join(out, "kernel_stats_timed_window.txt"), "w") as fh:
+            fh.write(json.dumps(summary["force_kernel_timed_window"], indent=1) + "\n")
 json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary.get("force_kernel", {}), indent=1))
 print(json.dumps(summary.get("calibration", {}), indent=1))

@@ -428,7 +428,9 @@ def main():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.melt < 0:
-        args.melt = 200 if (args.workload == "lj" and args.gpus == 1 and not args.decomp) else 0
+        # every lj run melts, whatever the number of GPUs: the driver computes scaling efficiency from the per-N lines, which must
+        # time the same physical state
+        args.melt = 200 if args.workload == "lj" else 0
     if args.pmc_child:  # a counter pass: the same workload, a few steps, nothing else
         args.steps, args.warmup, args.no_cpu_baseline, args.no_live_pmc = 6, 2, True, True
     if args.workload != "lj":

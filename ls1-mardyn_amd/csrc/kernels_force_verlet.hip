@@ -234,6 +234,23 @@ __device__ __forceinline__ ListHead load_list_head(const ForceParams& P, int bri
 	return h;
 }
 
+// the four pairs of one list word (entries = LDS byte offsets of the partners' x)
+template <bool SHIFT, bool SIG1>
+__device__ __forceinline__ void pairs_of_word(const char* sxb, double xi, double yi, double zi, uint64_t cur, double rc2, double sig2,
+											  VAcc& acc) {
+	constexpr int CAPS = VCAPS;
+	const uint32_t lo32 = (uint32_t)cur, hi32 = (uint32_t)(cur >> 32);
+	const uint32_t o[4] = {lo32 & 0xffffu, lo32 >> 16, hi32 & 0xffffu, hi32 >> 16};
+	double xj[4], yj[4], zj[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		xj[k] = *reinterpret_cast<const double*>(sxb + o[k]);
+		yj[k] = *reinterpret_cast<const double*>(sxb + o[k] + CAPS * 8);
+		zj[k] = *reinterpret_cast<const double*>(sxb + o[k] + 2 * CAPS * 8);
+	}
+	v_pair4<SHIFT, SIG1>(xi, yi, zi, xj, yj, zj, rc2, sig2, acc);
+}
+
 // Forces of the owned molecules of ONE brick from the stored lists (positions staged in sx / sy / sz, table in T).
 template <bool SHIFT, bool SIG1 = false>
 __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTab& T, const double* sx, const double* sy,
@@ -244,15 +261,70 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const uint32_t total = T.cstart[VNRC], n_i = T.bstart[NBC];
 	const double rc2 = P.rc2, eps24 = P.eps24, sig2 = P.sig2, shift6 = P.shift6;
+	// Split tile (see below; a regular brick has at most VMAXT * 64 = 640 owned molecules, i.e. it is always the SECOND pass): lane
+	// mapping, own indices and word count are requested here, ahead of the first pass's pair loop — behind it they would be a
+	// chain of dependent round trips on one wave with the rest of the workgroup waiting
+	static_assert(VMAXT * 64 <= 2 * VNT, "split tiles: second pass only");
+	uint32_t sp_ii = total, sp_gi = 0, sp_nw = 4u;
+	// lane mapping of the split tile: molecule m and share s of this lane, lg = log2 of the lanes per molecule (recomputed
+	// where it is used: three registers less across the first pass's pair loop)
+	struct SplitMap {
+		uint32_t m, s, lg;
+		bool any, own;
+	};
+	auto split_map = [&]() {
+		SplitMap r = {0u, 0u, 0u, false, false};
+		const uint32_t wbase = (uint32_t)NT + (uint32_t)wv * 64u;
+		const uint32_t n_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_i);
+		r.any = wbase < n_u;
+		if (r.any) {
+			const uint32_t left = min(64u, n_u - wbase);
+			r.lg = left <= 8u ? 3u : left <= 16u ? 2u : left <= 32u ? 1u : 0u;
+			r.m = (uint32_t)lane & ((64u >> r.lg) - 1u);
+			r.s = (uint32_t)lane >> (6u - r.lg);
+			r.own = r.m < left;
+		}
+		return r;
+	};
+#ifndef LS1_NO_SPLIT_TAIL
+	if (fast_ii != nullptr) {
+		const SplitMap sm = split_map();
+		if (sm.any) {
+			const uint32_t wbase = (uint32_t)NT + (uint32_t)wv * 64u;
+			if (sm.own) sp_ii = (uint32_t)fast_ii[wbase + sm.m];
+			if (sm.own && sm.s == 0u) sp_gi = fast_gi[wbase + sm.m];
+			sp_nw = (uint32_t)P.vl_nw[(size_t)brick_id * VMAXT + (uint32_t)(NW + wv)];
+		}
+	}
+#endif
 	for (uint32_t base = 0, pass = 0; base < n_i; base += NT, ++pass) {
 		const uint32_t it = base + (uint32_t)tid;
-		const bool active = it < n_i;
+		bool active = it < n_i;
 		const uint32_t tile = pass * NW + (uint32_t)wv;  // wave-uniform
 		const bool listed = staged && tile < (uint32_t)VMAXT;
 		const size_t tile_g = (size_t)brick_id * VMAXT + tile;
 		uint32_t ii = total, gi = 0;
 		int rowbase = 0;
-		if (active && fast_ii) {  // regular brick: own LDS slot and global index as recorded by the build (no table search)
+#ifndef LS1_NO_SPLIT_TAIL
+		// LEFTOVER TILES of a regular brick (the molecules beyond the 512th: a brick of the aligned grid owns 512 on average, so
+		// every second brick has a handful).  One lane per molecule would run a whole pair loop for them on one wave while the
+		// other seven wait: the tile is split instead — 8 / 4 / 2 lanes per molecule, lane (m, s) takes the word rows s, s + S, ...
+		// of molecule m's list, the partial sums are combined across the lanes of a molecule, lane (m, 0) runs the epilogue.
+		const bool split = pass != 0 && fast_ii != nullptr;
+#else
+		const bool split = false;
+#endif
+		uint32_t sp_m = 0, sp_s = 0, sp_lg = 0;
+		if (split) {
+			const SplitMap sm = split_map();
+			if (!sm.any) continue;  // wave-uniform: this wave has no molecule in the tile
+			sp_m = sm.m;
+			sp_s = sm.s;
+			sp_lg = sm.lg;
+			active = sm.own && sm.s == 0u;
+			ii = sp_ii;
+			gi = sp_gi;
+		} else if (active && fast_ii) {  // regular brick: own LDS slot and global index as recorded by the build (no table search)
 			ii = pass == 0 ? ii0 : (uint32_t)fast_ii[it];  // first pass: loaded by the caller ahead of the staging
 			gi = pass == 0 ? gi0 : fast_gi[it];
 		} else if (active) {
@@ -283,8 +355,51 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 			vz0 = P.vz[gi];
 		}
 		uint32_t nw = 0xffu;
-		if (listed) nw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pass == 0 ? head.nw : (uint32_t)P.vl_nw[tile_g]));
-		if (nw != 0xffu) {
+		if (split) nw = (uint32_t)__builtin_amdgcn_readfirstlane((int)sp_nw);  // (a regular brick: the tile is listed)
+		else if (listed) nw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pass == 0 ? head.nw : (uint32_t)P.vl_nw[tile_g]));
+		if (split) {
+			const double xi = sx[ii], yi = sy[ii], zi = sz[ii];  // lanes without a molecule: the dummy slot, dummy words
+			const uint64_t* const wpm = P.vl_words + tile_g * VMAXW * 64 + sp_m;
+			const char* const sxb = reinterpret_cast<const char*>(sx);
+			const uint64_t dummy = (uint64_t)(total * 8u) * 0x0001000100010001ull;
+			const uint32_t st = 1u << sp_lg, lastw = nw - 1u, trips = (nw + st - 1u) >> sp_lg;
+			uint32_t w0 = sp_s, w1 = sp_s + st;
+			// two rows in flight, one loop-carried register each (see below); rows past the end: clamped load, dummy word
+			uint64_t c0 = load_row(wpm + (size_t)min(w0, lastw) * 64), c1 = load_row(wpm + (size_t)min(w1, lastw) * 64);
+			for (uint32_t k = 0; k < trips; k += 2) {
+				pairs_of_word<SHIFT, SIG1>(sxb, xi, yi, zi, w0 < nw ? c0 : dummy, rc2, sig2, acc);
+				w0 += 2u * st;
+				c0 = load_row(wpm + (size_t)min(w0, lastw) * 64);
+				if (k + 1 < trips) pairs_of_word<SHIFT, SIG1>(sxb, xi, yi, zi, w1 < nw ? c1 : dummy, rc2, sig2, acc);
+				w1 += 2u * st;
+				c1 = load_row(wpm + (size_t)min(w1, lastw) * 64);
+			}
+			// the shares of a molecule: lanes m, m + 64 / S, ... (fixed order: the same bits on every run)
+			if (sp_lg >= 1u) {
+				acc.fx += __shfl_xor(acc.fx, 32);
+				acc.fy += __shfl_xor(acc.fy, 32);
+				acc.fz += __shfl_xor(acc.fz, 32);
+				acc.slj += __shfl_xor(acc.slj, 32);
+				acc.vir += __shfl_xor(acc.vir, 32);
+				acc.nin += (uint32_t)__shfl_xor((int)acc.nin, 32);
+			}
+			if (sp_lg >= 2u) {
+				acc.fx += __shfl_xor(acc.fx, 16);
+				acc.fy += __shfl_xor(acc.fy, 16);
+				acc.fz += __shfl_xor(acc.fz, 16);
+				acc.slj += __shfl_xor(acc.slj, 16);
+				acc.vir += __shfl_xor(acc.vir, 16);
+				acc.nin += (uint32_t)__shfl_xor((int)acc.nin, 16);
+			}
+			if (sp_lg >= 3u) {
+				acc.fx += __shfl_xor(acc.fx, 8);
+				acc.fy += __shfl_xor(acc.fy, 8);
+				acc.fz += __shfl_xor(acc.fz, 8);
+				acc.slj += __shfl_xor(acc.slj, 8);
+				acc.vir += __shfl_xor(acc.vir, 8);
+				acc.nin += (uint32_t)__shfl_xor((int)acc.nin, 8);
+			}
+		} else if (nw != 0xffu) {
 			const double xi = sx[ii], yi = sy[ii], zi = sz[ii];  // inactive lanes: the dummy slot (their words are all dummies)
 			const uint64_t* const wp = P.vl_words + tile_g * VMAXW * 64 + lane;
 			const char* const sxb = reinterpret_cast<const char*>(sx);

@@ -174,7 +174,7 @@ extern "C" int ls1hip_destroy(ls1hip_ctx* c) {
 	hipStreamSynchronize(c->stream);
 	free_mol(c);
 	free_cells(c);
-	for (int k = 0; k < 3; ++k) dfree(c->brick_lists.d[k]);
+	for (int k = 0; k < 5; ++k) dfree(c->brick_lists.d[k]);
 	dfree(c->d_ct);
 	dfree(c->d_cnt);
 	dfree(c->d_stage);

@@ -46,6 +46,7 @@ struct BrickSel {
 	int x0, y0, z0;  // brick origin in grid cell coordinates
 	int ex, ey, ez;  // extent in cells (edge bricks are partial)
 	int id;          // linear brick index (bz * nby + by) * nbx + bx — independent of the launch order / pass
+	int did;         // index of the brick's neighbour-list data (ForceParams::did_mode)
 	bool live;
 };
 // vb / vgrid: (virtual) workgroup index and grid size — blockIdx.x / gridDim.x for one brick per workgroup; persistent
@@ -57,6 +58,8 @@ __device__ __forceinline__ BrickSel brick_select_v(const ForceParams& P, int nbx
 	const int slot = (vb % 8) * chunk + vb / 8;
 	BrickSel b;
 	b.live = vb < vgrid && slot < nb;
+	b.did = slot;
+	if (b.live && P.did_mode == 2) b.did = (int)P.brick_did[slot];
 	int bx = 0, by = 0, bz = 0;
 	if (b.live && P.inner_box) {
 		bx = P.inner_lo[0] + slot % P.inner_n[0];
@@ -69,6 +72,7 @@ __device__ __forceinline__ BrickSel brick_select_v(const ForceParams& P, int nbx
 		bz = brick / (nbx * nby);
 	}
 	b.id = (bz * nby + by) * nbx + bx;
+	if (P.did_mode == 0) b.did = b.id;
 	b.x0 = HW + bx * BX;
 	b.y0 = HW + by * BY;
 	b.z0 = HW + bz * BZ;

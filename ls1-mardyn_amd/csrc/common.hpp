@@ -79,6 +79,11 @@ struct ForceParams {
 	int count_pairs;
 	const uint32_t* brick_list;  // brick kernels: bricks of this pass (boundary), nullptr = all bricks / inner box
 	uint32_t n_list;
+	// neighbour-list kernels: where the per-brick data (record, lists, own indices) of the brick of launch slot k lives —
+	// 0: at the brick's linear index; 1: at k (the launch runs over ALL bricks in the blocked order, and the data is stored in
+	// that order: nothing at the head of a workgroup waits for the brick_list lookup); 2: at brick_did[k] (inner / boundary passes)
+	int did_mode;
+	const uint32_t* brick_did;
 	// inner pass: the inner bricks form a box of bricks [lo, lo + n) per dimension — indexed arithmetically (a list lookup
 	// puts a dependent global load in front of every workgroup: ~1 us x 105 rounds on the 2.4 ms inner pass)
 	int inner_box, inner_lo[3], inner_n[3];
@@ -103,8 +108,10 @@ struct ForceParams {
 // inner / boundary brick lists of the LJ brick kernels for the current grid and brick shape (kernels_force_lj.hip)
 struct BrickLists {
 	int shape[3] = {0, 0, 0}, dims[3] = {0, 0, 0}, hw = 0;
-	uint32_t* d[3] = {nullptr, nullptr, nullptr};  // inner bricks, boundary bricks, all bricks (each in blocked order)
-	uint32_t n[3] = {0, 0, 0};
+	// [0] inner bricks, [1] boundary bricks, [2] all bricks (each in blocked order); [3] / [4]: for every entry of [0] / [1] its
+	// position in [2] (the index of the brick's list data, see ForceParams::did_mode)
+	uint32_t* d[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+	uint32_t n[5] = {0, 0, 0, 0, 0};
 };
 
 struct Timer {

@@ -661,7 +661,7 @@ static bool brick_lists_for(BrickLists* bl, const Grid& g, int BX, int BY, int B
 		int a, b, c;
 		if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) BB[0] = a, BB[1] = b, BB[2] = c;
 	}
-	std::vector<uint32_t> lst[3];
+	std::vector<uint32_t> lst[5];
 	for (int Z = 0; Z < nbz; Z += BB[2])
 		for (int Y = 0; Y < nby; Y += BB[1])
 			for (int X = 0; X < nbx; X += BB[0])
@@ -675,9 +675,10 @@ static bool brick_lists_for(BrickLists* bl, const Grid& g, int BX, int BY, int B
 											   y0 + ey <= g.dims[1] - 2 * hw && z0 + ez <= g.dims[2] - 2 * hw;
 							const uint32_t id = (uint32_t)((bz * nby + by) * nbx + bx);
 							lst[inner ? 0 : 1].push_back(id);
+							lst[inner ? 3 : 4].push_back((uint32_t)lst[2].size());
 							lst[2].push_back(id);
 						}
-	for (int k = 0; k < 3; ++k) {
+	for (int k = 0; k < 5; ++k) {
 		if (bl->d[k]) (void)hipFree(bl->d[k]);
 		bl->d[k] = nullptr;
 		bl->n[k] = (uint32_t)lst[k].size();
@@ -705,9 +706,13 @@ long plan_bricks(ForceParams& p, BrickLists* bl, int BX, int BY, int BZ, int nbx
 	p.brick_list = nullptr;
 	p.n_list = 0;
 	p.inner_box = 0;
+	p.did_mode = 0;
+	p.brick_did = nullptr;
 	if (p.which == 1 && blocked_order && brick_lists_for(bl, p.g, BX, BY, BZ, nbx, nby, nbz)) {
 		p.brick_list = bl->d[0];  // the inner bricks in the blocked launch order
 		p.n_list = bl->n[0];
+		p.did_mode = 2;
+		p.brick_did = bl->d[3];
 		n = p.n_list;
 	} else if (p.which == 1) {
 		// "inner" is separable per dimension: bricks [lo, lo + cnt) whose cells lie in [2hw, dims - 2hw)
@@ -731,10 +736,15 @@ long plan_bricks(ForceParams& p, BrickLists* bl, int BX, int BY, int BZ, int nbx
 	} else if (p.which == 2 && brick_lists_for(bl, p.g, BX, BY, BZ, nbx, nby, nbz)) {
 		p.brick_list = bl->d[1];
 		p.n_list = bl->n[1];
+		if (blocked_order) {
+			p.did_mode = 2;
+			p.brick_did = bl->d[4];
+		}
 		n = p.n_list;
 	} else if (p.which == 0 && blocked_order && brick_lists_for(bl, p.g, BX, BY, BZ, nbx, nby, nbz)) {
 		p.brick_list = bl->d[2];  // every brick, in the blocked launch order
 		p.n_list = bl->n[2];
+		p.did_mode = 1;
 	}
 	return 8 * ((n + 7) / 8);
 }

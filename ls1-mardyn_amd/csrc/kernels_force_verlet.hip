@@ -261,42 +261,9 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const uint32_t total = T.cstart[VNRC], n_i = T.bstart[NBC];
 	const double rc2 = P.rc2, eps24 = P.eps24, sig2 = P.sig2, shift6 = P.shift6;
-	// Split tile (see below; a regular brick has at most VMAXT * 64 = 640 owned molecules, i.e. it is always the SECOND pass): lane
-	// mapping, own indices and word count are requested here, ahead of the first pass's pair loop — behind it they would be a
-	// chain of dependent round trips on one wave with the rest of the workgroup waiting
+	// Split tile (see below): a regular brick has at most VMAXT * 64 = 640 owned molecules, i.e. it is always the SECOND pass.
+	// (Requesting its indices and word count ahead of the first pass's pair loop was measured: no gain, three registers.)
 	static_assert(VMAXT * 64 <= 2 * VNT, "split tiles: second pass only");
-	uint32_t sp_ii = total, sp_gi = 0, sp_nw = 4u;
-	// lane mapping of the split tile: molecule m and share s of this lane, lg = log2 of the lanes per molecule (recomputed
-	// where it is used: three registers less across the first pass's pair loop)
-	struct SplitMap {
-		uint32_t m, s, lg;
-		bool any, own;
-	};
-	auto split_map = [&]() {
-		SplitMap r = {0u, 0u, 0u, false, false};
-		const uint32_t wbase = (uint32_t)NT + (uint32_t)wv * 64u;
-		const uint32_t n_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_i);
-		r.any = wbase < n_u;
-		if (r.any) {
-			const uint32_t left = min(64u, n_u - wbase);
-			r.lg = left <= 8u ? 3u : left <= 16u ? 2u : left <= 32u ? 1u : 0u;
-			r.m = (uint32_t)lane & ((64u >> r.lg) - 1u);
-			r.s = (uint32_t)lane >> (6u - r.lg);
-			r.own = r.m < left;
-		}
-		return r;
-	};
-#ifndef LS1_NO_SPLIT_TAIL
-	if (fast_ii != nullptr) {
-		const SplitMap sm = split_map();
-		if (sm.any) {
-			const uint32_t wbase = (uint32_t)NT + (uint32_t)wv * 64u;
-			if (sm.own) sp_ii = (uint32_t)fast_ii[wbase + sm.m];
-			if (sm.own && sm.s == 0u) sp_gi = fast_gi[wbase + sm.m];
-			sp_nw = (uint32_t)P.vl_nw[(size_t)brick_id * VMAXT + (uint32_t)(NW + wv)];
-		}
-	}
-#endif
 	for (uint32_t base = 0, pass = 0; base < n_i; base += NT, ++pass) {
 		const uint32_t it = base + (uint32_t)tid;
 		bool active = it < n_i;
@@ -314,16 +281,20 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 #else
 		const bool split = false;
 #endif
-		uint32_t sp_m = 0, sp_s = 0, sp_lg = 0;
+		uint32_t sp_m = 0, sp_s = 0, sp_lg = 0, sp_nw = 4u;  // molecule and share of this lane, log2 of the lanes per molecule
 		if (split) {
-			const SplitMap sm = split_map();
-			if (!sm.any) continue;  // wave-uniform: this wave has no molecule in the tile
-			sp_m = sm.m;
-			sp_s = sm.s;
-			sp_lg = sm.lg;
-			active = sm.own && sm.s == 0u;
-			ii = sp_ii;
-			gi = sp_gi;
+			const uint32_t wbase = base + (uint32_t)wv * 64u;
+			const uint32_t n_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_i);
+			if (wbase >= n_u) continue;  // wave-uniform: this wave has no molecule in the tile
+			const uint32_t left = min(64u, n_u - wbase);
+			sp_lg = left <= 8u ? 3u : left <= 16u ? 2u : left <= 32u ? 1u : 0u;
+			sp_m = (uint32_t)lane & ((64u >> sp_lg) - 1u);
+			sp_s = (uint32_t)lane >> (6u - sp_lg);
+			const bool own = sp_m < left;
+			active = own && sp_s == 0u;
+			if (own) ii = (uint32_t)fast_ii[wbase + sp_m];
+			if (active) gi = fast_gi[wbase + sp_m];
+			sp_nw = (uint32_t)P.vl_nw[tile_g];
 		} else if (active && fast_ii) {  // regular brick: own LDS slot and global index as recorded by the build (no table search)
 			ii = pass == 0 ? ii0 : (uint32_t)fast_ii[it];  // first pass: loaded by the caller ahead of the staging
 			gi = pass == 0 ? gi0 : fast_gi[it];
@@ -737,7 +708,7 @@ __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int n
 	const BrickTab T = {cstart, gbeg, bstart};
 	block_tables(P, bs, T, wsum);
 	const uint32_t total = cstart[VNRC], n_i = bstart[NBC];
-	uint32_t* const rec = P.vl_rec + (size_t)bs.id * VREC;
+	uint32_t* const rec = P.vl_rec + (size_t)bs.did * VREC;
 	if (total > (uint32_t)VCAPJ) {  // unstaged brick: evaluated directly every step, no lists
 		// an empty record: the force pass stages from the record BEFORE it looks at the flags (nothing to stage here)
 		for (int c = tid; c < VREC; c += NT) rec[c] = 0;
@@ -824,7 +795,7 @@ __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int n
 		const bool active = it < n_i;
 		const uint32_t tile = pass * VNW + (uint32_t)wv;  // wave-uniform
 		if (tile >= (uint32_t)VMAXT) continue;          // tiles beyond the list capacity are evaluated directly
-		const size_t tile_g = (size_t)bs.id * VMAXT + tile;
+		const size_t tile_g = (size_t)bs.did * VMAXT + tile;
 		uint64_t* const wp = P.vl_words + tile_g * VMAXW * 64 + lane;
 		uint32_t cnt = 0;
 		if (active) {
@@ -838,8 +809,8 @@ __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int n
 			const int rcell = ((cz + 1) * RY + (cy + 1)) * RX + (cx + 1);
 			const uint32_t ii = cstart[rcell] + (it - bstart[lo]);
 			const int rowbase = (cz * RY + cy) * RX + cx;
-			P.vl_ii[(size_t)bs.id * (VMAXT * 64) + it] = (uint16_t)ii;
-			P.vl_gi[(size_t)bs.id * (VMAXT * 64) + it] = gbeg[rcell] + (it - bstart[lo]);
+			P.vl_ii[(size_t)bs.did * (VMAXT * 64) + it] = (uint16_t)ii;
+			P.vl_gi[(size_t)bs.did * (VMAXT * 64) + it] = gbeg[rcell] + (it - bstart[lo]);
 			const f32x2 xi = {fpos[3 * ii], fpos[3 * ii]}, yi = {fpos[3 * ii + 1], fpos[3 * ii + 1]}, zi = {fpos[3 * ii + 2], fpos[3 * ii + 2]};
 			// Search in two phases per block of 32 candidates.  SCAN: distance test of every candidate, its outcome shifted into a
 			// per-lane bit mask by the compare's carry (v_cmp + v_addc: two instructions of bookkeeping per candidate; the first
@@ -947,8 +918,8 @@ __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int n
 }
 
 // ---- REUSE, one brick per workgroup (reference implementation of the pipeline below; LS1_VL_ONE_BRICK_PER_WG) ---------
-template <bool SHIFT, bool SIG1>
-__global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet(ForceParams P, int nbx, int nby, int nbz) {
+template <bool SHIFT, bool SIG1, bool FAST>
+__global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet(ForceParams P, int nbx, int nby, int nbz, int vgrid) {
 	constexpr int CAPS = VCAPS;
 	__shared__ double spos[3 * CAPS];
 	double* const sx = spos;
@@ -960,8 +931,25 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet(ForceParams P, int n
 	__shared__ uint32_t wsum[VNW];
 	__shared__ double red[VNW][4];
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	const BrickSel bs = brick_select<1, VBX, VBY, VBZ>(P, nbx, nby, nbz);
-	if (!bs.live) {  // uniform per workgroup
+	// FAST HEAD (the production launch: every brick, blocked order, per-brick data stored in launch order — did_mode 1): the
+	// workgroup's data index is pure arithmetic on blockIdx.x; the brick's identity (one dependent scalar load) and its grid
+	// coordinates (three integer divisions) are not needed before the end of a regular brick, so nothing at the head waits for
+	// them.  Every other launch (inner / boundary passes, plain order) resolves the brick first, as before.
+	constexpr bool fast_head = FAST;  // (chosen by the host from did_mode: one head per instantiation, no register cost)
+	BrickSel bs;
+	bool live;
+	int did, slot = 0;
+	if constexpr (fast_head) {
+		const int vb = (int)blockIdx.x, chunk = vgrid / 8;
+		slot = (vb % 8) * chunk + vb / 8;
+		live = slot < (int)P.n_list;
+		did = slot;
+	} else {
+		bs = brick_select_v<1, VBX, VBY, VBZ>(P, nbx, nby, nbz, (int)blockIdx.x, vgrid);
+		live = bs.live;
+		did = bs.did;
+	}
+	if (!live) {  // uniform per workgroup
 		if (tid < 4) P.partials[(size_t)blockIdx.x * 4 + tid] = 0.;
 		return;
 	}
@@ -976,11 +964,11 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet(ForceParams P, int n
 	if (blockIdx.x >= 256u && blockIdx.x < 512u)
 		for (int i = 0; i < LS1_STAGGER_MOCK; ++i) __builtin_amdgcn_s_sleep(127);
 #endif
-	uint32_t* const rec = P.vl_rec + (size_t)bs.id * VREC;
+	uint32_t* const rec = P.vl_rec + (size_t)did * VREC;
 	// own LDS slot / global index of the first pass, issued together with the list head and the flags (reads of valid memory
 	// whatever the flags say): nothing the pair loop needs is requested after the staging barrier
-	const uint16_t* const f_ii = P.vl_ii + (size_t)bs.id * (VMAXT * 64);
-	const uint32_t* const f_gi = P.vl_gi + (size_t)bs.id * (VMAXT * 64);
+	const uint16_t* const f_ii = P.vl_ii + (size_t)did * (VMAXT * 64);
+	const uint32_t* const f_gi = P.vl_gi + (size_t)did * (VMAXT * 64);
 	uint32_t ii0 = 0, gi0 = 0;
 	// Staging straight from the build's record, BEFORE the flags are looked at: the descriptor loads leave first, ahead of the
 	// list head and the own indices, instead of behind a dependent flag load (an unstaged brick has an empty record).
@@ -988,7 +976,7 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet(ForceParams P, int n
 	// two more HBM round trips.)
 	{
 		const BrickTab R = {rec, rec + VREC_GBEG, nullptr};
-		head = load_list_head(P, bs.id, wv, lane);  // list head and own indices: independent of everything staged below
+		head = load_list_head(P, did, wv, lane);  // list head and own indices: independent of everything staged below
 		ii0 = f_ii[tid];
 		gi0 = f_gi[tid];
 #ifdef LS1_NOSTAGE_MOCK
@@ -1005,16 +993,18 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet(ForceParams P, int n
 		// regular brick (staged, every tile has its list): cell table and own indices come from the build's record — no cell
 		// loads, no scans, no table search; the only barrier of the workgroup is the one behind the staging
 		const BrickTab T = {cstart, gbeg, bstart};  // (only the two totals are read on this path)
-		brick_forces<SHIFT, SIG1>(P, T, sx, sy, sz, bs.id, true, head, tot, f_ii, f_gi, ii0, gi0);
+		brick_forces<SHIFT, SIG1>(P, T, sx, sy, sz, did, true, head, tot, f_ii, f_gi, ii0, gi0);
+		store_partials(P, tot, red, fast_head ? (int)P.brick_list[slot] : bs.id);
 	} else {
+		if constexpr (fast_head) bs = brick_select_v<1, VBX, VBY, VBZ>(P, nbx, nby, nbz, (int)blockIdx.x, vgrid);
 		const BrickTab T = {cstart, gbeg, bstart};
 		block_tables(P, bs, T, wsum);
 		const bool staged = cstart[VNRC] <= (uint32_t)VCAPJ;
 		if (staged) stage_positions(P, T, sx, sy, sz);
 		__syncthreads();
-		brick_forces<SHIFT, SIG1>(P, T, sx, sy, sz, bs.id, staged, head, tot);
+		brick_forces<SHIFT, SIG1>(P, T, sx, sy, sz, did, staged, head, tot);
+		store_partials(P, tot, red, bs.id);
 	}
-	store_partials(P, tot, red, bs.id);
 }
 
 
@@ -1062,10 +1052,10 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet_sp(ForceParams P, in
 		if (tid < 4) P.partials[(size_t)blockIdx.x * 4 + tid] = 0.;
 		return;
 	}
-	const ListHead head = load_list_head(P, bs.id, wv, lane);
-	const uint32_t* const rec = P.vl_rec + (size_t)bs.id * VREC;
-	const uint16_t* const f_ii = P.vl_ii + (size_t)bs.id * (VMAXT * 64);
-	const uint32_t* const f_gi = P.vl_gi + (size_t)bs.id * (VMAXT * 64);
+	const ListHead head = load_list_head(P, bs.did, wv, lane);
+	const uint32_t* const rec = P.vl_rec + (size_t)bs.did * VREC;
+	const uint16_t* const f_ii = P.vl_ii + (size_t)bs.did * (VMAXT * 64);
+	const uint32_t* const f_gi = P.vl_gi + (size_t)bs.did * (VMAXT * 64);
 	const uint32_t ii0 = f_ii[tid], gi0 = f_gi[tid];
 	const uint32_t total = rec[VNRC], n_i = rec[VREC_NI];
 	// ---- staging: FP32 relative to the low corner of the region's first cell (as the build does) ------------------------------
@@ -1141,7 +1131,7 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet_sp(ForceParams P, in
 		const uint32_t it = base + (uint32_t)tid;
 		const bool active = it < n_i;
 		const uint32_t tile = pass * NW + (uint32_t)wv;  // wave-uniform; < VMAXT (regular brick)
-		const size_t tile_g = (size_t)bs.id * VMAXT + tile;
+		const size_t tile_g = (size_t)bs.did * VMAXT + tile;
 		uint32_t ii = total, gi = 0;
 		if (active) {
 			ii = pass == 0 ? ii0 : (uint32_t)f_ii[it];
@@ -1307,6 +1297,9 @@ bool launch_force_verlet(const ForceParams& p_in, hipStream_t s, uint32_t* nbloc
 		return e ? atoi(e) != 0 : true;
 	}();
 	const long nb = plan_bricks(p, bl, VBX, VBY, VBZ, nbx, nby, nbz, blocked);  // multiple of 8
+	// the per-brick data is stored in the blocked order: a launch that cannot have it (no brick lists: allocation failure) must
+	// not run against data another launch stored that way
+	if (blocked && p.did_mode == 0) return false;
 	if (nb == 0) {
 		*nblocks = 0;
 		return true;
@@ -1328,7 +1321,15 @@ bool launch_force_verlet(const ForceParams& p_in, hipStream_t s, uint32_t* nbloc
 	} else {
 		const bool sig1 = p.sig2 == 1.0;  // reduced units: one multiplication less per pair, same bits
 		auto go = [&](auto sh, auto s1) {
-			hipLaunchKernelGGL((k_force_lj_verlet<decltype(sh)::value, decltype(s1)::value>), dim3((uint32_t)nb), dim3(VNT), 0, s, p, nbx, nby, nbz);
+#ifdef LS1_NO_FAST_HEAD
+			const bool fast = false;  // (A/B switch, tools/ab_variant.sh)
+#else
+			const bool fast = p.did_mode == 1;
+#endif
+			if (fast)
+				hipLaunchKernelGGL((k_force_lj_verlet<decltype(sh)::value, decltype(s1)::value, true>), dim3((uint32_t)nb), dim3(VNT), 0, s, p, nbx, nby, nbz, (int)nb);
+			else
+				hipLaunchKernelGGL((k_force_lj_verlet<decltype(sh)::value, decltype(s1)::value, false>), dim3((uint32_t)nb), dim3(VNT), 0, s, p, nbx, nby, nbz, (int)nb);
 		};
 		if (shift && sig1) go(std::true_type{}, std::true_type{});
 		else if (shift) go(std::true_type{}, std::false_type{});

@@ -255,11 +255,11 @@ __device__ __forceinline__ void pairs_of_word(const char* sxb, double xi, double
 template <bool SHIFT, bool SIG1 = false>
 __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTab& T, const double* sx, const double* sy,
 											 const double* sz, int brick_id, bool staged, const ListHead& head, Totals& tot,
-											 const uint16_t* fast_ii = nullptr, const uint32_t* fast_gi = nullptr, uint32_t ii0 = 0,
-											 uint32_t gi0 = 0) {
+											 uint32_t total, uint32_t n_i, const uint16_t* fast_ii = nullptr,
+											 const uint32_t* fast_gi = nullptr, uint32_t ii0 = 0, uint32_t gi0 = 0) {
 	constexpr int NT = VNT, NW = VNW, RX = VRX, RY = VRY, BX = VBX, BY = VBY, NBC = VNBC, CAPS = VCAPS;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	const uint32_t total = T.cstart[VNRC], n_i = T.bstart[NBC];
+	// total = molecules of the staged region, n_i = owned molecules: from the build's record (scalars) or from the tables in T
 	const double rc2 = P.rc2, eps24 = P.eps24, sig2 = P.sig2, shift6 = P.shift6;
 	// Split tile (see below): a regular brick has at most VMAXT * 64 = 640 owned molecules, i.e. it is always the SECOND pass.
 	// (Requesting its indices and word count ahead of the first pass's pair loop was measured: no gain, three registers.)
@@ -613,12 +613,16 @@ __device__ __forceinline__ void block_tables(const ForceParams& P, const BrickSe
 struct NoOp {
 	__device__ void operator()() const {}
 };
-template <class F = NoOp>
+struct TotalOf {  // region total known up front
+	uint32_t v;
+	__device__ uint32_t operator()() const { return v; }
+};
+template <class TOT, class F = NoOp>
 __device__ __forceinline__ void stage_positions(const ForceParams& P, const BrickTab& T, double* sx, double* sy, double* sz,
-												F after_issue = F()) {
+												TOT total_of, F after_issue = F()) {
 	constexpr int NR = (VNRC + VNT / 16 - 1) / (VNT / 16);  // rounds of cells per 16-lane group
 	const int tid = threadIdx.x;
-	const uint32_t sub = (uint32_t)tid & 15u, total = T.cstart[VNRC];
+	const uint32_t sub = (uint32_t)tid & 15u;
 	double px[NR][2], py[NR][2], pz[NR][2];
 	uint32_t sdst[NR][2];
 	bool more = false;
@@ -673,6 +677,7 @@ __device__ __forceinline__ void stage_positions(const ForceParams& P, const Bric
 			}
 		}
 	}
+	const uint32_t total = total_of();  // (evaluated here: behind the position loads and their stores)
 	if (tid < 8) {
 		sx[total + tid] = VFAR;
 		sy[total + tid] = VFAR;
@@ -965,6 +970,10 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet(ForceParams P, int n
 		for (int i = 0; i < LS1_STAGGER_MOCK; ++i) __builtin_amdgcn_s_sleep(127);
 #endif
 	uint32_t* const rec = P.vl_rec + (size_t)did * VREC;
+	// the record's three scalars (region total, owned count, flags; uniform addresses = scalar loads).  Forcing them out at the
+	// head (inline asm) and requesting all kernel arguments of the later phases in one batch was measured: no gain (± 0.3 %) —
+	// the other workgroup of the CU hides scalar round trips of this size
+	const uint32_t rec_total = rec[VNRC], rec_ni = rec[VREC_NI], rec_flags = rec[VREC_FLAGS];
 	// own LDS slot / global index of the first pass, issued together with the list head and the flags (reads of valid memory
 	// whatever the flags say): nothing the pair loop needs is requested after the staging barrier
 	const uint16_t* const f_ii = P.vl_ii + (size_t)did * (VMAXT * 64);
@@ -982,27 +991,23 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet(ForceParams P, int n
 #ifdef LS1_NOSTAGE_MOCK
 		if (P.which != 0)  // run-time false: the staging is skipped
 #endif
-		stage_positions(P, R, sx, sy, sz);
-		if (tid == 0) {
-			cstart[VNRC] = rec[VNRC];
-			bstart[VNBC] = rec[VREC_NI];
-		}
+		stage_positions(P, R, sx, sy, sz, TotalOf{rec_total});
 	}
 	__syncthreads();
-	if (rec[VREC_FLAGS] & 1u) {  // uniform per workgroup
+	if (rec_flags & 1u) {  // uniform per workgroup
 		// regular brick (staged, every tile has its list): cell table and own indices come from the build's record — no cell
 		// loads, no scans, no table search; the only barrier of the workgroup is the one behind the staging
 		const BrickTab T = {cstart, gbeg, bstart};  // (only the two totals are read on this path)
-		brick_forces<SHIFT, SIG1>(P, T, sx, sy, sz, did, true, head, tot, f_ii, f_gi, ii0, gi0);
+		brick_forces<SHIFT, SIG1>(P, T, sx, sy, sz, did, true, head, tot, rec_total, rec_ni, f_ii, f_gi, ii0, gi0);
 		store_partials(P, tot, red, fast_head ? (int)P.brick_list[slot] : bs.id);
 	} else {
 		if constexpr (fast_head) bs = brick_select_v<1, VBX, VBY, VBZ>(P, nbx, nby, nbz, (int)blockIdx.x, vgrid);
 		const BrickTab T = {cstart, gbeg, bstart};
 		block_tables(P, bs, T, wsum);
 		const bool staged = cstart[VNRC] <= (uint32_t)VCAPJ;
-		if (staged) stage_positions(P, T, sx, sy, sz);
+		if (staged) stage_positions(P, T, sx, sy, sz, TotalOf{cstart[VNRC]});
 		__syncthreads();
-		brick_forces<SHIFT, SIG1>(P, T, sx, sy, sz, did, staged, head, tot);
+		brick_forces<SHIFT, SIG1>(P, T, sx, sy, sz, did, staged, head, tot, cstart[VNRC], bstart[VNBC]);
 		store_partials(P, tot, red, bs.id);
 	}
 }

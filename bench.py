@@ -422,6 +422,8 @@ def main():
     ap.add_argument("--melt", type=int, default=-1,
                     help="untimed device steps BEFORE the warm-up steps (lj workload: default 200 — the lattice start melts, list "
                          "lengths spread; the timed window is then steady state)")
+    ap.add_argument("--long-run", type=int, default=200,
+                    help="lj workload, one GPU: steps of the secondary long window after the timed one (0 = none)")
     ap.add_argument("--rebuild-every", type=int, default=10,
                     help="mixed workload (static configuration): the lists are rebuilt every this many traversals, the interval the "
                          "moving workloads measure")
@@ -595,10 +597,12 @@ def main():
     e.timing_reset()
     e.timing_enable(2)  # the timed region carries the HIP-event pairs of the force launches only (roofline.avg_launch_ms)
     sync()
+    builds_before = int(e.get_option("verlet_builds")) if args.workload == "lj" else 0
     t0 = time.perf_counter()
     last = run(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
+    builds_in_window = (int(e.get_option("verlet_builds")) - builds_before) if args.workload == "lj" else None
     e.timing_enable(0)
     force_ms, force_n = e.timing("force")
     # per-phase device times: a few extra steps with every phase timed, OUTSIDE the timed region
@@ -608,6 +612,20 @@ def main():
     run(nprof)
     sync()
     e.timing_enable(0)
+    long_run = None
+    if args.workload == "lj" and world == 1 and not args.pmc_child and args.long_run > 0:
+        # secondary figure: a window long enough to average over the list lifetimes.  A rebuild step costs ~3 ordinary steps and comes
+        # every ~11 steps, so a K-step window holds floor or ceil of K / 10.8 of them: +- 2 % on 50 steps, +- 5 % on the driver's 20
+        b0 = int(e.get_option("verlet_builds"))
+        sync()
+        t_l = time.perf_counter()
+        run(args.long_run)
+        sync()
+        dt_l = time.perf_counter() - t_l
+        long_run = {"steps": args.long_run, "ms_per_step": dt_l / args.long_run * 1e3,
+                    "list_builds": int(e.get_option("verlet_builds")) - b0,
+                    "note": "run AFTER the timed window and the profiling steps; NOT the headline — the headline's K steps hold an "
+                            "integer number of list rebuilds (see `builds_in_timed_window`), this window averages over them"}
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
@@ -723,6 +741,11 @@ def main():
         if lattice is not None:
             lattice["value"] = n_total / (lattice["ms_per_step"] * 1e-3)
             out["lattice_start"] = lattice
+        if builds_in_window is not None and out["config"]["neighbour_lists"]:
+            out["config"]["neighbour_lists"]["builds_in_timed_window"] = builds_in_window
+        if long_run:
+            long_run["value"] = n_total / (long_run["ms_per_step"] * 1e-3)
+            out["long_run"] = long_run
         if live_compute is not None:
             out["roofline"]["compute"] = live_compute
         elif pmc_extra:

@@ -291,6 +291,13 @@ int ls1hip_halo_refresh(ls1hip_ctx* ctx);
  * Follow with ls1hip_forces_list (list mode) or ls1hip_forces. */
 int ls1hip_update(ls1hip_ctx* ctx, int* rebuilt);
 int ls1hip_forces_list(ls1hip_ctx* ctx, int which, double dt, double* upot, double* virial);
+/* List traversal of ALL cells that also does the step's post-force kick (Leapfrog::transition2to3 -> FullMolecule::upd_postF,
+ * integrators/Leapfrog.cpp:66-150) in its epilogue: v += dt_half / m F with the kinetic sum of thermostat 0 (fetch it with
+ * ls1hip_kinetic_sums), F is kept — the pass ls1hip_run takes on unfused steps (NVT, the last step), for drivers that call the
+ * pieces themselves (the reference driver through LinkedCellsHip / LeapfrogHip: one pass over the molecules less per step).
+ * Single-centre LJ list path only (read-only option "list_kick_available"); otherwise LS1HIP_EINVAL — use
+ * ls1hip_forces_list + ls1hip_kick. */
+int ls1hip_forces_list_kick(ls1hip_ctx* ctx, double dt_half, double* upot, double* virial);
 int ls1hip_verlet_poll(ls1hip_ctx* ctx, int* need_rebuild);
 
 /* nsteps full time steps entirely on the device (single rank, all directions local), no host round trip

@@ -65,6 +65,7 @@ SYMBOLS = {
     "ls1hip_halo_refresh": (C.c_int, [C.c_void_p]),
     "ls1hip_update": (C.c_int, [C.c_void_p, _ip]),
     "ls1hip_forces_list": (C.c_int, [C.c_void_p, C.c_int, C.c_double, _dp, _dp]),
+    "ls1hip_forces_list_kick": (C.c_int, [C.c_void_p, C.c_double, _dp, _dp]),
     "ls1hip_verlet_poll": (C.c_int, [C.c_void_p, _ip]),
     "ls1hip_run": (C.c_int, [C.c_void_p, C.c_double, C.c_ulong, _dp]),
     "ls1hip_run_log": (C.c_int, [C.c_void_p, C.c_size_t, _dp, C.POINTER(C.c_size_t)]),

@@ -280,6 +280,7 @@ extern "C" int ls1hip_get_option(const ls1hip_ctx* c, const char* name, long* v)
 		}
 	} else if (n == "precision_in_use") *v = (c->opt_precision && c->vl_ready && c->vl_all_regular) ? c->opt_precision : 0;
 	else if (n == "can_fuse_integration") *v = can_fuse(c) ? 1 : 0;
+	else if (n == "list_kick_available") *v = (c->vl_ready && c->one_clj) ? 1 : 0;
 	else if (n == "last_force_kernel") *v = c->last_force_kernel;
 	else if (n == "verlet_lists") *v = c->vl_on ? 1 : 0;
 	else if (n == "verlet_ready") *v = c->vl_ready ? 1 : 0;
@@ -1678,7 +1679,13 @@ static int forces_list_impl(ls1hip_ctx* c, int which, double dt, bool post_kick,
 extern "C" int ls1hip_forces_list(ls1hip_ctx* c, int which, double dt, double* upot, double* virial) {
 	return forces_list_impl(c, which, dt, false, upot, virial);
 }
-// post_kick (internal, ls1hip_run): dt is the time step, the pass is NOT fused with the drift but does the post-force kick and
+extern "C" int ls1hip_forces_list_kick(ls1hip_ctx* c, double dt_half, double* upot, double* virial) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, dt_half > 0., "dt_half must be > 0");
+	REQUIRE(c, c->one_clj, "the post-force kick is folded into the single-centre LJ list pass only (ls1hip_forces_list + ls1hip_kick)");
+	return forces_list_impl(c, 0, 2. * dt_half, true, upot, virial);
+}
+// post_kick (ls1hip_run, ls1hip_forces_list_kick): dt is the time step, the pass is NOT fused with the drift but does the post-force kick and
 // the kinetic sum of the step itself (F is stored); which must be 0
 static int forces_list_impl(ls1hip_ctx* c, int which, double dt, bool post_kick, double* upot, double* virial) {
 	if (!c) return LS1HIP_EINVAL;

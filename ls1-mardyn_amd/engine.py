@@ -278,6 +278,15 @@ class DeviceEngine:
         self._chk(self.lib.ls1hip_forces_list(self.ctx, int(which), float(dt), C.byref(u), C.byref(w)))
         return u.value, w.value
 
+    def forces_list_kick(self, dt_half: float, want_macro: bool = False):
+        """list traversal + the step's post-force kick in one pass (ls1hip_forces_list_kick); kinetic sums: kinetic_sums()"""
+        if not want_macro:
+            self._chk(self.lib.ls1hip_forces_list_kick(self.ctx, float(dt_half), None, None))
+            return None
+        u = C.c_double(); w = C.c_double()
+        self._chk(self.lib.ls1hip_forces_list_kick(self.ctx, float(dt_half), C.byref(u), C.byref(w)))
+        return u.value, w.value
+
     def verlet_poll(self) -> bool:
         n = C.c_int()
         self._chk(self.lib.ls1hip_verlet_poll(self.ctx, C.byref(n)))

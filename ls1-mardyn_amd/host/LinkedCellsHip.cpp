@@ -35,6 +35,34 @@
 
 using Log::global_log;
 
+// LS1HIP_PROFILE=1: host wall time spent inside the device container / integrator entry points, printed at the last step — what of
+// the driver's per-step time is ours (queueing + waiting for the device) and what is the driver's own host work
+#include <chrono>
+namespace {
+struct HostProfile {
+	bool on = getenv("LS1HIP_PROFILE") != nullptr;
+	std::map<std::string, std::pair<double, unsigned long>> t;
+	void report() {
+		if (!on) return;
+		for (auto& it : t)
+			global_log->info() << "LS1HIP_PROFILE " << it.first << ": " << it.second.first << " s in " << it.second.second << " calls" << std::endl;
+	}
+} g_prof;
+struct ProfScope {
+	const char* name;
+	std::chrono::steady_clock::time_point t0;
+	explicit ProfScope(const char* n) : name(n) {
+		if (g_prof.on) t0 = std::chrono::steady_clock::now();
+	}
+	~ProfScope() {
+		if (!g_prof.on) return;
+		auto& e = g_prof.t[name];
+		e.first += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		e.second++;
+	}
+};
+}  // namespace
+
 void LinkedCellsHip::die(const char* what, int rc) const {
 	global_log->error() << "LinkedCellsHip: " << what << " failed (" << rc << "): " << ls1hip_last_error(_ctx) << std::endl;
 	Simulation::exit(680 - rc);
@@ -51,7 +79,7 @@ LinkedCellsHip::~LinkedCellsHip() {
 	if (_ctx) ls1hip_destroy(_ctx);
 }
 
-void LinkedCellsHip::readXML(XMLfileUnits& xmlconfig) { _mirror.readXML(xmlconfig); }
+void LinkedCellsHip::readXML(XMLfileUnits& xmlconfig) { mirror().readXML(xmlconfig); }
 
 bool LinkedCellsHip::rebuild(double bBoxMin[3], double bBoxMax[3]) {
 	for (int d = 0; d < 3; ++d) {
@@ -59,7 +87,7 @@ bool LinkedCellsHip::rebuild(double bBoxMin[3], double bBoxMax[3]) {
 		_boundingBoxMax[d] = bBoxMax[d];
 	}
 	_hostDirty = true;  // the device grid is derived from the box at the next upload
-	return _mirror.rebuild(bBoxMin, bBoxMax);
+	return mirror().rebuild(bBoxMin, bBoxMax);
 }
 
 // ---- host-side population: everything goes to the mirror ---------------------------------------------------------------
@@ -68,7 +96,7 @@ bool LinkedCellsHip::addParticle(Molecule& particle, bool inBoxCheckedAlready, b
 	if (_inExchange) return false;  // (unreachable: the exchange window sees empty region iterators)
 	if (!_mirrorFresh) syncMirrorFromDevice();
 	_hostDirty = true;
-	return _mirror.addParticle(particle, inBoxCheckedAlready, checkWhetherDuplicate, rebuildCaches);
+	return mirror().addParticle(particle, inBoxCheckedAlready, checkWhetherDuplicate, rebuildCaches);
 }
 
 bool LinkedCellsHip::addHaloParticle(Molecule& particle, bool inBoxCheckedAlready, bool checkWhetherDuplicate,
@@ -81,18 +109,18 @@ bool LinkedCellsHip::addHaloParticle(Molecule& particle, bool inBoxCheckedAlread
 void LinkedCellsHip::addParticles(std::vector<Molecule>& particles, bool checkWhetherDuplicate) {
 	if (!_mirrorFresh) syncMirrorFromDevice();
 	_hostDirty = true;
-	_mirror.addParticles(particles, checkWhetherDuplicate);
+	mirror().addParticles(particles, checkWhetherDuplicate);
 }
 
 unsigned long LinkedCellsHip::initCubicGrid(std::array<unsigned long, 3> numMoleculesPerDimension,
 											std::array<double, 3> simBoxLength, size_t seed_offset) {
 	_hostDirty = true;
 	_mirrorFresh = true;
-	return _mirror.initCubicGrid(numMoleculesPerDimension, simBoxLength, seed_offset);
+	return mirror().initCubicGrid(numMoleculesPerDimension, simBoxLength, seed_offset);
 }
 
 void LinkedCellsHip::clear() {
-	_mirror.clear();
+	mirror().clear();
 	_mirrorFresh = true;
 	_hostDirty = true;
 	_uploaded = false;
@@ -100,18 +128,18 @@ void LinkedCellsHip::clear() {
 
 void LinkedCellsHip::deleteMolecule(ParticleIterator& moleculeIter, const bool& rebuildCaches) {
 	// the iterator can only point into a fresh mirror (a stale one is empty inside the host-loop windows and refilled outside)
-	_mirror.deleteMolecule(moleculeIter, rebuildCaches);
+	mirror().deleteMolecule(moleculeIter, rebuildCaches);
 	_hostDirty = true;
 }
 
 double LinkedCellsHip::getEnergy(ParticlePairsHandler* particlePairsHandler, Molecule* m1, CellProcessor& cellProcessor) {
 	if (!_mirrorFresh) syncMirrorFromDevice();
-	return _mirror.getEnergy(particlePairsHandler, m1, cellProcessor);  // grand-canonical insertions: host path of the reference
+	return mirror().getEnergy(particlePairsHandler, m1, cellProcessor);  // grand-canonical insertions: host path of the reference
 }
 
 std::variant<ParticleIterator, SingleCellIterator<ParticleCell>> LinkedCellsHip::getMoleculeAtPosition(const double pos[3]) {
 	if (!_mirrorFresh) syncMirrorFromDevice();  // a point query has no per-step caller in the driver: always the real molecules
-	return _mirror.getMoleculeAtPosition(pos);
+	return mirror().getMoleculeAtPosition(pos);
 }
 
 // Who iterates a stale mirror?  Inside the two windows below it is the driver's own per-step host loops, whose work the device has
@@ -138,6 +166,7 @@ void LinkedCellsHip::stepClosed() {
 }
 
 void LinkedCellsHip::ensureMirror() {
+	ProfScope prof_("ensureMirror");
 	if (_mirrorFresh || !_uploaded || inHostLoopWindow()) return;
 	// iterator() may be called by every thread of a parallel region at once (LinkedCells.h:245-250): one of them refills
 #if defined(_OPENMP)
@@ -150,34 +179,42 @@ void LinkedCellsHip::ensureMirror() {
 	}
 }
 
+void LinkedCellsHip::joinClear() {
+	if (_clearJob.valid()) _clearJob.get();
+}
+
 ParticleIterator LinkedCellsHip::iterator(ParticleIterator::Type t) {
+	ProfScope prof_("iterator");
 	ensureMirror();
-	return _mirror.iterator(t);
+	if (!_mirrorFresh) return ParticleIterator();  // the driver's per-step host loops over a stale mirror: nothing to visit
+	return mirror().iterator(t);
 }
 
 RegionParticleIterator LinkedCellsHip::regionIterator(const double startCorner[3], const double endCorner[3],
 													   ParticleIterator::Type t) {
 	if (_inExchange) return RegionParticleIterator();  // DomainDecompBase::exchangeMolecules: done on the device
 	ensureMirror();
-	return _mirror.regionIterator(startCorner, endCorner, t);
+	if (!_mirrorFresh) return RegionParticleIterator();
+	return mirror().regionIterator(startCorner, endCorner, t);
 }
 
 unsigned long LinkedCellsHip::getNumberOfParticles() {
+	ProfScope prof_("getNumberOfParticles");
 	if (_uploaded && !_hostDirty) {
 		size_t n = 0, h = 0;
 		ls1hip_count(_ctx, &n, &h);
 		return (unsigned long)n;
 	}
-	return _mirror.getNumberOfParticles();
+	return mirror().getNumberOfParticles();
 }
 
 std::vector<unsigned long> LinkedCellsHip::getParticleCellStatistics() {
 	ensureMirror();
-	return _mirror.getParticleCellStatistics();
+	return mirror().getParticleCellStatistics();
 }
-std::string LinkedCellsHip::getConfigurationAsString() { return _mirror.getConfigurationAsString() + " (device-resident, libls1hip)"; }
-size_t LinkedCellsHip::getTotalSize() { return _mirror.getTotalSize(); }
-void LinkedCellsHip::printSubInfo(int offset) { _mirror.printSubInfo(offset); }
+std::string LinkedCellsHip::getConfigurationAsString() { return mirror().getConfigurationAsString() + " (device-resident, libls1hip)"; }
+size_t LinkedCellsHip::getTotalSize() { return mirror().getTotalSize(); }
+void LinkedCellsHip::printSubInfo(int offset) { mirror().printSubInfo(offset); }
 
 // ---- device side ------------------------------------------------------------------------------------------------------------
 void LinkedCellsHip::uploadFromMirror() {
@@ -200,28 +237,28 @@ void LinkedCellsHip::uploadFromMirror() {
 	if ((rc = ls1hip_set_components_from(_ctx, *(sim->getEnsemble()->getComponents()), *domain, sim->getcutoffRadius(),
 										 sim->getLJCutoff())))
 		die("ls1hip_set_components", rc);
-	if ((rc = ls1hip_set_option(_ctx, "cells_in_cutoff", _mirror.getHaloWidthNumCells()))) die("ls1hip_set_option", rc);
+	if ((rc = ls1hip_set_option(_ctx, "cells_in_cutoff", mirror().getHaloWidthNumCells()))) die("ls1hip_set_option", rc);
 	// neighbour lists with a skin (ls1hip_set_verlet): on by default with 8 % of the cutoff, LS1HIP_SKIN=<length> overrides,
 	// LS1HIP_SKIN=0 keeps the reference's search-every-step scheme.  The engine falls back by itself where lists do not apply
 	// (multi-site components, two cells per cutoff, regions beyond its staging capacity).
 	_skin = 0.08 * sim->getcutoffRadius();
 	if (const char* e = getenv("LS1HIP_SKIN")) _skin = atof(e);
-	if (_mirror.getHaloWidthNumCells() != 1) _skin = 0.;
+	if (mirror().getHaloWidthNumCells() != 1) _skin = 0.;
 	if (_multiRank) _skin = 0.;  // the multi-rank seam of the driver searches every step (the list-mode exchange is the handed-over loop's)
 	if ((rc = ls1hip_set_verlet(_ctx, _skin > 0. ? 1 : 0, _skin))) die("ls1hip_set_verlet", rc);
 	double glen[3], bmin[3], bmax[3];
 	int nbr[27];
 	for (int d = 0; d < 3; ++d) {
 		glen[d] = domain->getGlobalLength(d);
-		bmin[d] = _mirror.getBoundingBoxMin(d);
-		bmax[d] = _mirror.getBoundingBoxMax(d);
+		bmin[d] = mirror().getBoundingBoxMin(d);
+		bmax[d] = mirror().getBoundingBoxMax(d);
 	}
 	for (int k = 0; k < 27; ++k) nbr[k] = 0;  // DomainDecompBase: every side is periodic onto this rank
 	if (_multiRank) dd->neighbourTable(glen, nbr);
 	if ((rc = ls1hip_set_domain(_ctx, glen, bmin, bmax, _multiRank ? dd->getRank() : 0, nbr))) die("ls1hip_set_domain", rc);
 	// streamed in chunks straight from the mirror's iterator (a full copy in six vectors next to the mirror's Molecule objects
 	// cost ~17 GB of host memory more at 10^8 molecules): the announced total is an upper bound that sizes the device arrays
-	const unsigned long n0 = _mirror.getNumberOfParticles();
+	const unsigned long n0 = mirror().getNumberOfParticles();
 	constexpr size_t CHUNK = 1u << 20;
 	std::vector<uint64_t> id(CHUNK);
 	std::vector<int32_t> cid(CHUNK);
@@ -232,7 +269,7 @@ void LinkedCellsHip::uploadFromMirror() {
 		if (k && (rc = ls1hip_upload_chunk(_ctx, k, id.data(), cid.data(), r.data(), v.data(), q.data(), D.data()))) die("ls1hip_upload_chunk", rc);
 		k = 0;
 	};
-	for (auto m = _mirror.iterator(ParticleIterator::ONLY_INNER_AND_BOUNDARY); m.isValid(); ++m) {
+	for (auto m = mirror().iterator(ParticleIterator::ONLY_INNER_AND_BOUNDARY); m.isValid(); ++m) {
 		id[k] = m->getID();
 		cid[k] = (int32_t)m->componentid();
 		for (int d = 0; d < 3; ++d) {
@@ -250,12 +287,13 @@ void LinkedCellsHip::uploadFromMirror() {
 }
 
 void LinkedCellsHip::update() {
+	ProfScope prof_("update");
 	if (_hostDirty || !_uploaded) {
 		if (!_mirrorFresh) {
 			global_log->error() << "LinkedCellsHip: molecules were changed on the host while the mirror was stale" << std::endl;
 			Simulation::exit(682);
 		}
-		_mirror.update();
+		mirror().update();
 		uploadFromMirror();
 	}
 	if (_multiRank) {
@@ -284,16 +322,17 @@ void LinkedCellsHip::exchangeAcrossRanks(DomainDecompHip& dd, Domain* domain) {
 
 void LinkedCellsHip::updateMoleculeCaches() {
 	_inExchange = false;  // (the halo was populated / refreshed by ls1hip_update)
-	if (_mirrorFresh) _mirror.updateMoleculeCaches();  // keeps calcFM on mirror molecules (prepare_start) well defined
+	if (_mirrorFresh) mirror().updateMoleculeCaches();  // keeps calcFM on mirror molecules (prepare_start) well defined
 }
 void LinkedCellsHip::updateInnerMoleculeCaches() {}
 void LinkedCellsHip::updateBoundaryAndHaloMoleculeCaches() { updateMoleculeCaches(); }
 
 void LinkedCellsHip::deleteOuterParticles() {
-	if (_mirrorFresh) _mirror.deleteOuterParticles();  // device: the halo segment is rebuilt by every ls1hip_halo
+	if (_mirrorFresh) mirror().deleteOuterParticles();  // device: the halo segment is rebuilt by every ls1hip_halo
 }
 
 void LinkedCellsHip::deviceForces(int which) {
+	ProfScope prof_("deviceForces");
 	double upot = 0., virial = 0.;
 	const bool want = which != 1;
 	long lists = 0;
@@ -301,7 +340,18 @@ void LinkedCellsHip::deviceForces(int which) {
 	// The kernels are only queued here.  With the integrator's post-force kick armed (LeapfrogHip::eventNewTimestep) it is
 	// queued right behind the traversal, and the host waits for the traversal's sums only: the kick runs on the device while the
 	// driver does its host work between traverseCells and eventForcesCalculated (long-range correction, timers, plugins).
-	int rc = lists ? ls1hip_forces_list(_ctx, which, 0., nullptr, nullptr) : ls1hip_forces(_ctx, which, nullptr, nullptr);
+	// single-centre LJ list path, complete traversal: the pass does the armed post-force kick and its kinetic sum in its own
+	// epilogue (ls1hip_forces_list_kick) — one pass over the molecules less per step
+	long fold = 0;
+	if (lists && which == 0 && _armedKick > 0.) ls1hip_get_option(_ctx, "list_kick_available", &fold);
+	int rc;
+	if (fold) {
+		rc = ls1hip_forces_list_kick(_ctx, _armedKick, nullptr, nullptr);
+		_armedKick = 0.;
+		_kickQueued = true;
+	} else {
+		rc = lists ? ls1hip_forces_list(_ctx, which, 0., nullptr, nullptr) : ls1hip_forces(_ctx, which, nullptr, nullptr);
+	}
 	if (rc) die("ls1hip_forces", rc);
 	if (want) {
 		if ((rc = ls1hip_traversal_mark(_ctx))) die("ls1hip_traversal_mark", rc);
@@ -345,7 +395,11 @@ void LinkedCellsHip::deviceAdvanced() {
 	_quietArmed = false;
 	_betaPending = false;  // (the integrator has just applied the factors on the device)
 	if (_mirrorFresh) {
-		_mirror.clear();  // stale from here on: its iterators stay valid and yield nothing
+		// stale from here on: iterator() yields nothing without touching the mirror.  LinkedCells::clear (LinkedCells.cpp:590-595)
+		// walks the cells serially — 50 ms at 10^7 molecules, inside the driver's timed loop (emptying the cells through the
+		// container's parallel iterator was measured: 84 ms) — so it runs on a helper thread; every other user of the mirror
+		// waits for it (joinClear)
+		_clearJob = std::async(std::launch::async, [this] { _mirror.clear(); });
 		_mirrorFresh = false;
 	}
 }
@@ -371,7 +425,7 @@ void LinkedCellsHip::syncMirrorFromDevice(bool applyPendingBeta) {
 	if (rc) die("ls1hip_download_state", rc);
 	const bool haveF = ls1hip_download_forces(_ctx, n, F.data(), M.data(), nullptr) == LS1HIP_OK;
 	std::vector<Component>& comps = *(global_simulation->getEnsemble()->getComponents());
-	_mirror.clear();
+	mirror().clear();
 	std::vector<Molecule> mols;
 	mols.reserve(n);
 	for (size_t i = 0; i < n; ++i) {
@@ -385,8 +439,8 @@ void LinkedCellsHip::syncMirrorFromDevice(bool applyPendingBeta) {
 		}
 		mols.push_back(m);
 	}
-	_mirror.addParticles(mols);
-	_mirror.updateMoleculeCaches();
+	mirror().addParticles(mols);
+	mirror().updateMoleculeCaches();
 	_mirrorFresh = true;
 	_hostDirty = false;
 }
@@ -410,6 +464,7 @@ void LeapfrogHip::readXML(XMLfileUnits& xmlconfig) {
 void LeapfrogHip::init() { _state = STATE_POST_FORCE_CALCULATION; }
 
 void LeapfrogHip::eventNewTimestep(ParticleContainer* moleculeContainer, Domain* domain) {
+	ProfScope prof_("eventNewTimestep");
 	if (_state != STATE_POST_FORCE_CALCULATION) return;
 	LinkedCellsHip* cont = device_container(moleculeContainer);
 	ls1hip_ctx* ctx = cont->context();
@@ -436,7 +491,7 @@ void LeapfrogHip::eventNewTimestep(ParticleContainer* moleculeContainer, Domain*
 				global_log->error() << "ls1hip_scale_kick_drift_components: " << ls1hip_last_error(ctx) << std::endl;
 				Simulation::exit(686);
 			}
-		} else if ((rc = ls1hip_scale_kick_drift(ctx, domain->getGlobalBetaTrans(), domain->getGlobalBetaRot(), _timestepLength))) {
+		} else if ((rc = [&] { ProfScope p2("eNT.scale_kick_drift"); return ls1hip_scale_kick_drift(ctx, domain->getGlobalBetaTrans(), domain->getGlobalBetaRot(), _timestepLength); }())) {
 			global_log->error() << "ls1hip_scale_kick_drift: " << ls1hip_last_error(ctx) << std::endl;
 			Simulation::exit(686);
 		}
@@ -444,12 +499,16 @@ void LeapfrogHip::eventNewTimestep(ParticleContainer* moleculeContainer, Domain*
 		global_log->error() << "ls1hip_kick_drift: " << ls1hip_last_error(ctx) << std::endl;
 		Simulation::exit(687);
 	}
-	cont->deviceAdvanced();
+	{
+		ProfScope p3("eNT.deviceAdvanced");
+		cont->deviceAdvanced();
+	}
 	cont->armPostForceKick(0.5 * _timestepLength);
 	_state = STATE_PRE_FORCE_CALCULATION;
 }
 
 void LeapfrogHip::eventForcesCalculated(ParticleContainer* moleculeContainer, Domain* domain) {
+	ProfScope prof_("eventForcesCalculated");
 	if (_state != STATE_PRE_FORCE_CALCULATION) return;
 	LinkedCellsHip* cont = device_container(moleculeContainer);
 	ls1hip_ctx* ctx = cont->context();
@@ -509,6 +568,7 @@ void LeapfrogHip::eventForcesCalculated(ParticleContainer* moleculeContainer, Do
 		ls1hip_get_option(ctx, "verlet_lists", &on);
 		ls1hip_get_option(ctx, "verlet_builds", &builds);
 		ls1hip_get_option(ctx, "verlet_steps", &evals);
+		g_prof.report();
 		global_log->info() << "LinkedCellsHip: neighbour lists " << (on ? "on" : "off") << ": " << builds << " builds for " << evals
 						   << " list force evaluations" << std::endl;
 	}

@@ -26,6 +26,7 @@
 // empty container.
 #pragma once
 #include <array>
+#include <future>
 #include <string>
 #include <variant>
 #include <vector>
@@ -111,6 +112,14 @@ private:
 	void deviceForces(int which);
 
 	LinkedCells _mirror;  // host mirror: the reference's own container (all host-side semantics)
+	// LinkedCells::clear of a stale mirror runs on a helper thread (LinkedCellsHip::deviceAdvanced); everything that touches the
+	// mirror's molecules goes through mirror(), which waits for it.  (Declared after _mirror: destroyed — i.e. joined — before it.)
+	std::future<void> _clearJob;
+	void joinClear();
+	LinkedCells& mirror() {
+		joinClear();
+		return _mirror;
+	}
 	ls1hip_ctx* _ctx = nullptr;
 	double _skin = 0.;          // neighbour-list skin handed to ls1hip_set_verlet (0: search every step)
 	double _armedKick = 0.;     // dt / 2 of the integrator's post-force kick, queued behind the next traversal

@@ -245,3 +245,33 @@ def test_single_precision_list_loop_against_reference_sp_trajectory(name):
     assert abs(out["virial"] - g["virial"]) <= 5e-6 * abs(g["virial"])
     assert abs(out["summv2"] - g["summv2"]) <= 1e-6 * abs(g["summv2"])
     e.close()
+
+
+def test_list_pass_with_folded_post_force_kick_equals_pass_plus_kick():
+    """ls1hip_forces_list_kick (the piecewise form of what ls1hip_run does on unfused steps; used by LinkedCellsHip for the
+    reference driver): forces, U_pot, virial of ls1hip_forces_list, velocities and sum m v^2 of ls1hip_kick
+    (Leapfrog::transition2to3, Leapfrog.cpp:66-150) — and F against the reference's golden."""
+    name = "bcc1clj_16000"
+    g = read_golden(name)
+    dt_half = 0.001
+    out = []
+    for folded in (False, True):
+        case, ps, st, e = _production_engine(name, 0.2)
+        assert e.update() is True
+        assert e.get_option("list_kick_available") == 1
+        if folded:
+            u, w = e.forces_list_kick(dt_half, want_macro=True)
+            kin = e.kinetic_sums()
+        else:
+            u, w = e.forces_list(0, 0.0, want_macro=True)
+            kin = e.kick(dt_half)
+        _assert_production_path(e)
+        ids, r, v, F = _sorted(e)
+        out.append((u, w, kin, v, F))
+        e.close()
+    (u0, w0, k0, v0, F0), (u1, w1, k1, v1, F1) = out
+    assert rel_max(F1, g["recs"]["F"]) < 1e-10
+    assert np.array_equal(F0, F1) and u0 == u1 and w0 == w1
+    assert np.max(np.abs(v1 - v0)) <= 1e-15 * np.max(np.abs(v0))
+    assert abs(k1[0] - k0[0]) <= 1e-13 * abs(k0[0])  # sum m v^2 (different summation order)
+    assert k1[2] == k0[2] == 16000

@@ -34,6 +34,10 @@ for skin in ("default", "0"):
     if out.returncode != 0:
         print(out.stdout[-2000:], out.stderr[-2000:])
         sys.exit(1)
+    if os.environ.get("SEAM_B_TIMERS"):  # the driver's own timer table
+        for ln in out.stdout.splitlines():
+            if "LS1HIP_PROFILE" in ln or ((" took" in ln or "speed" in ln) and "took: 0 sec" not in ln):
+                print("   ", ln.strip())
     speed = re.search(r"Simulation speed:\s*([0-9.eE+-]+)", out.stdout)
     lists = re.search(r"neighbour lists (on|off): (\d+) builds for (\d+)", out.stdout)
     comp = re.search(r"Computation took:\s*([0-9.eE+-]+)", out.stdout)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The reference driver's own `Simulation speed` line (MarDyn.cpp:253-266) with the device container + integrator (seam B,
 oracle/_ref/MarDyn_hipB) at BASELINE configs[1]: 1CLJ, N = 2*171^3 = 10 000 422 from the reference's CubicGridGenerator, NVT as
-every shipped config, 100 steps, no output plugins, no final checkpoint.   usage: python tools/seam_b_speed.py [n_per_dim] [steps]"""
+every shipped config, 100 steps, no output plugins, no final checkpoint.   usage: python tools/seam_b_speed.py [n_per_dim] [steps] [lists-only]"""
 import os
 import re
 import subprocess
@@ -21,7 +21,8 @@ cfg = HEAD.format(dt=0.002, steps=steps, temp=0.95, L=repr(L), rc=2.5, component
                   phasespace='<generator name="CubicGridGenerator"><specification>density</specification>'
                              '<density>0.785302672</density><binaryMixture>false</binaryMixture></generator>')
 binary = os.path.join(ROOT, "oracle", "_ref", "MarDyn_hipB")
-for skin in ("default", "0"):
+skins = ("default",) if len(sys.argv) > 3 and sys.argv[3] == "lists-only" else ("default", "0")
+for skin in skins:
     with tempfile.TemporaryDirectory() as td:
         open(os.path.join(td, "config.xml"), "w").write(cfg)
         env = dict(os.environ, OMP_NUM_THREADS="16")

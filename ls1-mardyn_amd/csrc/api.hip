@@ -1370,29 +1370,37 @@ extern "C" int ls1hip_set_thermostat(ls1hip_ctx* c, int enabled, double target_t
 }
 
 // ---- Homogeneous long-range correction: longRange/Homogeneous.cpp ---------------------------------------------------
+// Tail (r > rc, homogeneous fluid) of one term (sigma^2 / r^2)^(-n) of a site-site potential, angle-averaged over the
+// orientations of the two molecules; a, b = distances of the two sites from their molecules' centres.  The closed forms
+// (Lustig 1988; longRange/Homogeneous.cpp:137-180) are written here through the differences of powers they are made of:
+//   both sites central      u = -rc^m / (sigma^2n m),                              m = 2 n + 3
+//   one eccentric site      first differences  d1(k) = (rc + a)^k - (rc - a)^k
+//   two eccentric sites     second differences d2(k) over rc +- (a + b), rc +- (a - b)
+// u: energy integral, v: virial integral.
 namespace lrc {
-static double TICCu(int n, double rc, double s2) { return -pow(rc, 2 * n + 3) / (pow(s2, n) * (2 * n + 3)); }
-static double TICSu(int n, double rc, double s2, double tau) {
-	return -(pow(rc + tau, 2 * n + 3) - pow(rc - tau, 2 * n + 3)) * rc / (4 * pow(s2, n) * tau * (n + 1) * (2 * n + 3)) +
-		   (pow(rc + tau, 2 * n + 4) - pow(rc - tau, 2 * n + 4)) / (4 * pow(s2, n) * tau * (n + 1) * (2 * n + 3) * (2 * n + 4));
-}
-static double TISSu(int n, double rc, double s2, double t1, double t2) {
-	const double tp = t1 + t2, tm = t1 - t2;
-	return -(pow(rc + tp, 2 * n + 4) - pow(rc + tm, 2 * n + 4) - pow(rc - tm, 2 * n + 4) + pow(rc - tp, 2 * n + 4)) * rc /
-			   (8 * pow(s2, n) * t1 * t2 * (n + 1) * (2 * n + 3) * (2 * n + 4)) +
-		   (pow(rc + tp, 2 * n + 5) - pow(rc + tm, 2 * n + 5) - pow(rc - tm, 2 * n + 5) + pow(rc - tp, 2 * n + 5)) /
-			   (8 * pow(s2, n) * t1 * t2 * (n + 1) * (2 * n + 3) * (2 * n + 4) * (2 * n + 5));
-}
-static double TICCv(int n, double rc, double s2) { return 2 * n * TICCu(n, rc, s2); }
-static double TICSv(int n, double rc, double s2, double tau) {
-	return -(pow(rc + tau, 2 * n + 2) - pow(rc - tau, 2 * n + 2)) * rc * rc / (4 * pow(s2, n) * tau * (n + 1)) -
-		   3 * TICSu(n, rc, s2, tau);
-}
-static double TISSv(int n, double rc, double s2, double t1, double t2) {
-	const double tp = t1 + t2, tm = t1 - t2;
-	return -(pow(rc + tp, 2 * n + 3) - pow(rc + tm, 2 * n + 3) - pow(rc - tm, 2 * n + 3) + pow(rc - tp, 2 * n + 3)) * rc * rc /
-			   (8 * pow(s2, n) * t1 * t2 * (n + 1) * (2 * n + 3)) -
-		   3 * TISSu(n, rc, s2, t1, t2);
+struct Tail {
+	double u, v;
+};
+static Tail tail_term(int n, double rc, double s2, double a, double b) {
+	if (a < b) std::swap(a, b);  // (symmetric in the two sites)
+	const int m = 2 * n + 3;
+	const double sn = pow(s2, n);
+	Tail t;
+	if (a == 0.) {
+		t.u = -pow(rc, m) / (sn * m);
+		t.v = 2 * n * t.u;
+	} else if (b == 0.) {
+		auto d1 = [&](int k) { return pow(rc + a, k) - pow(rc - a, k); };
+		const double w = 1. / (4 * sn * a * (n + 1));
+		t.u = w * (d1(m + 1) / (m + 1) - rc * d1(m)) / m;
+		t.v = -w * rc * rc * d1(m - 1) - 3 * t.u;
+	} else {
+		auto d2 = [&](int k) { return pow(rc + a + b, k) - pow(rc + a - b, k) - pow(rc - a + b, k) + pow(rc - a - b, k); };
+		const double w = 1. / (8 * sn * a * b * (n + 1) * m);
+		t.u = w * (d2(m + 2) / (m + 2) - rc * d2(m + 1)) / (m + 1);
+		t.v = -w * rc * rc * d2(m) - 3 * t.u;
+	}
+	return t;
 }
 }  // namespace lrc
 
@@ -1423,22 +1431,15 @@ extern "C" int ls1hip_long_range_homogeneous(ls1hip_ctx* c, const uint64_t* nmol
 				const double tau1 = sqrt(pa[0] * pa[0] + pa[1] * pa[1] + pa[2] * pa[2]);
 				for (int b = 0; b < t.nlj[j]; ++b) {
 					const double* pb = t.ljpos[t.olj[j] + b];
-					double tau2 = sqrt(pb[0] * pb[0] + pb[1] * pb[1] + pb[2] * pb[2]);
+					const double tau2 = sqrt(pb[0] * pb[0] + pb[1] * pb[1] + pb[2] * pb[2]);
 					REQUIRE(c, tau1 + tau2 < rc, "error calculating cutoff corrections, rc too small");  // :83-86
 					const int k = (t.olj[i] + a) * t.ncenters + (t.olj[j] + b);
 					if (t.shift6[k] != 0.0) continue;  // truncated-shifted pairs carry no tail correction (:93)
 					const double fac = (double)nmol[i] * (double)nmol[j] * t.eps24[k], s2 = t.sig2[k];
-					if (tau1 == 0. && tau2 == 0.) {
-						U += fac * (lrc::TICCu(-6, rc, s2) - lrc::TICCu(-3, rc, s2));
-						V += fac * (lrc::TICCv(-6, rc, s2) - lrc::TICCv(-3, rc, s2));
-					} else if (tau1 != 0. && tau2 != 0.) {
-						U += fac * (lrc::TISSu(-6, rc, s2, tau1, tau2) - lrc::TISSu(-3, rc, s2, tau1, tau2));
-						V += fac * (lrc::TISSv(-6, rc, s2, tau1, tau2) - lrc::TISSv(-3, rc, s2, tau1, tau2));
-					} else {
-						if (tau2 == 0.) tau2 = tau1;
-						U += fac * (lrc::TICSu(-6, rc, s2, tau2) - lrc::TICSu(-3, rc, s2, tau2));
-						V += fac * (lrc::TICSv(-6, rc, s2, tau2) - lrc::TICSv(-3, rc, s2, tau2));
-					}
+					// LJ: 24 eps [(sigma/r)^12 - (sigma/r)^6] -> the n = -6 term minus the n = -3 term
+					const lrc::Tail t12 = lrc::tail_term(-6, rc, s2, tau1, tau2), t6 = lrc::tail_term(-3, rc, s2, tau1, tau2);
+					U += fac * (t12.u - t6.u);
+					V += fac * (t12.v - t6.v);
 				}
 			}
 	}

@@ -52,17 +52,27 @@ constexpr int VNRC = VRX * VRY * VRZ;  // 144 region cells
 constexpr int VNBC = VBX * VBY * VBZ;  // 32 brick cells
 #ifdef LS1_N3_MOCK
 constexpr int VCAPJ = 2560;            // TIMING MOCK of brick-internal Newton 3 (tools/ab_variant.sh): room for the LDS force accumulators
+#elif defined(LS1_POS_AOS)
+constexpr int VCAPJ = 2730;            // x y z of a molecule side by side (24 B): a u16 list entry = slot * 24 reaches 2730 slots
 #else
 constexpr int VCAPJ = 2816;            // staged molecules per brick region (67.8 KB of x, y, z)
 #endif
 constexpr int VCAPS = VCAPJ + 8;       // +8: the dummy slot and the overrun of unrolled row reads
+// layout of the staged positions: element (slot, c) at [VPS * slot + c * VCO]; list entry = byte offset of x = slot * VES (FP64 layout;
+// the single-precision pass halves it)
+#ifdef LS1_POS_AOS
+constexpr int VPS = 3, VCO = 1, VES = 24;
+static_assert(VCAPJ * VES < 65536, "list entries are u16 byte offsets");
+#else
+constexpr int VPS = 1, VCO = VCAPS, VES = 8;
+#endif
 constexpr int VMAXT = 10;    // tiles per brick with stored lists (640 owned molecules); further tiles: direct evaluation
 constexpr int VMAXW = 24;    // words per lane = 96 list entries
 // per-brick record written by the build: cstart[VNRC + 1], gbeg[VNRC], owned count, flags (bit 0: every tile listed, staged)
 constexpr int VREC_GBEG = VNRC + 1, VREC_NI = 2 * VNRC + 1, VREC_FLAGS = 2 * VNRC + 2, VREC = 2 * VNRC + 8;
 constexpr double VFAR = 1.0e30;  // dummy position: r^2 ~ 1e60 fails every cutoff test, all LJ terms underflow to 0
 static_assert(VNRC <= VNT * 4, "region too large for the block scan");
-static_assert(2 * VCAPS * 8 < 65536, "y / z are addressed as constant offsets from the x entry");
+static_assert(VCAPS * 8 < 65536, "list entries are u16 byte offsets");
 
 int verlet_region_capacity() { return VCAPJ; }
 int verlet_region_cells() { return VNRC; }
@@ -245,8 +255,8 @@ __device__ __forceinline__ void pairs_of_word(const char* sxb, double xi, double
 #pragma unroll
 	for (int k = 0; k < 4; ++k) {
 		xj[k] = *reinterpret_cast<const double*>(sxb + o[k]);
-		yj[k] = *reinterpret_cast<const double*>(sxb + o[k] + CAPS * 8);
-		zj[k] = *reinterpret_cast<const double*>(sxb + o[k] + 2 * CAPS * 8);
+		yj[k] = *reinterpret_cast<const double*>(sxb + o[k] + VCO * 8);
+		zj[k] = *reinterpret_cast<const double*>(sxb + o[k] + 2 * VCO * 8);
 	}
 	v_pair4<SHIFT, SIG1>(xi, yi, zi, xj, yj, zj, rc2, sig2, acc);
 }
@@ -329,10 +339,10 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 		if (split) nw = (uint32_t)__builtin_amdgcn_readfirstlane((int)sp_nw);  // (a regular brick: the tile is listed)
 		else if (listed) nw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pass == 0 ? head.nw : (uint32_t)P.vl_nw[tile_g]));
 		if (split) {
-			const double xi = sx[ii], yi = sy[ii], zi = sz[ii];  // lanes without a molecule: the dummy slot, dummy words
+			const double xi = sx[VPS * ii], yi = sy[VPS * ii], zi = sz[VPS * ii];  // lanes without a molecule: the dummy slot, dummy words
 			const uint64_t* const wpm = P.vl_words + tile_g * VMAXW * 64 + sp_m;
 			const char* const sxb = reinterpret_cast<const char*>(sx);
-			const uint64_t dummy = (uint64_t)(total * 8u) * 0x0001000100010001ull;
+			const uint64_t dummy = (uint64_t)(total * (uint32_t)VES) * 0x0001000100010001ull;
 			const uint32_t st = 1u << sp_lg, lastw = nw - 1u, trips = (nw + st - 1u) >> sp_lg;
 			uint32_t w0 = sp_s, w1 = sp_s + st;
 			// two rows in flight, one loop-carried register each (see below); rows past the end: clamped load, dummy word
@@ -371,7 +381,7 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 				acc.nin += (uint32_t)__shfl_xor((int)acc.nin, 8);
 			}
 		} else if (nw != 0xffu) {
-			const double xi = sx[ii], yi = sy[ii], zi = sz[ii];  // inactive lanes: the dummy slot (their words are all dummies)
+			const double xi = sx[VPS * ii], yi = sy[VPS * ii], zi = sz[VPS * ii];  // inactive lanes: the dummy slot (their words are all dummies)
 			const uint64_t* const wp = P.vl_words + tile_g * VMAXW * 64 + lane;
 			const char* const sxb = reinterpret_cast<const char*>(sx);
 			// Four word rows in flight (a row comes from HBM more often than from L2: the lists are read once per step).  Each
@@ -396,14 +406,14 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 			auto four_pairs = [&](uint64_t cur) {
 				const uint32_t lo32 = (uint32_t)cur, hi32 = (uint32_t)(cur >> 32);
 				const uint32_t o0 = lo32 & 0xffffu, o1 = lo32 >> 16, o2 = hi32 & 0xffffu, o3 = hi32 >> 16;
-				const double x0 = *reinterpret_cast<const double*>(sxb + o0), y0 = *reinterpret_cast<const double*>(sxb + o0 + CAPS * 8),
-							 z0 = *reinterpret_cast<const double*>(sxb + o0 + 2 * CAPS * 8);
-				const double x1 = *reinterpret_cast<const double*>(sxb + o1), y1 = *reinterpret_cast<const double*>(sxb + o1 + CAPS * 8),
-							 z1 = *reinterpret_cast<const double*>(sxb + o1 + 2 * CAPS * 8);
-				const double x2 = *reinterpret_cast<const double*>(sxb + o2), y2 = *reinterpret_cast<const double*>(sxb + o2 + CAPS * 8),
-							 z2 = *reinterpret_cast<const double*>(sxb + o2 + 2 * CAPS * 8);
-				const double x3 = *reinterpret_cast<const double*>(sxb + o3), y3 = *reinterpret_cast<const double*>(sxb + o3 + CAPS * 8),
-							 z3 = *reinterpret_cast<const double*>(sxb + o3 + 2 * CAPS * 8);
+				const double x0 = *reinterpret_cast<const double*>(sxb + o0), y0 = *reinterpret_cast<const double*>(sxb + o0 + VCO * 8),
+							 z0 = *reinterpret_cast<const double*>(sxb + o0 + 2 * VCO * 8);
+				const double x1 = *reinterpret_cast<const double*>(sxb + o1), y1 = *reinterpret_cast<const double*>(sxb + o1 + VCO * 8),
+							 z1 = *reinterpret_cast<const double*>(sxb + o1 + 2 * VCO * 8);
+				const double x2 = *reinterpret_cast<const double*>(sxb + o2), y2 = *reinterpret_cast<const double*>(sxb + o2 + VCO * 8),
+							 z2 = *reinterpret_cast<const double*>(sxb + o2 + 2 * VCO * 8);
+				const double x3 = *reinterpret_cast<const double*>(sxb + o3), y3 = *reinterpret_cast<const double*>(sxb + o3 + VCO * 8),
+							 z3 = *reinterpret_cast<const double*>(sxb + o3 + 2 * VCO * 8);
 #ifdef LS1_N3_MOCK
 				v_pair_n3<SHIFT, SIG1>(xi, yi, zi, x0, y0, z0, rc2, eps24, sig2, acc, (o0 >> 3) & 511u);
 				v_pair<SHIFT, SIG1>(xi, yi, zi, x1, y1, z1, rc2, eps24, sig2, acc);
@@ -454,12 +464,12 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 #endif
 		} else if (active && staged) {
 			// no stored list for this tile (list overflow, or more owned molecules than the list capacity covers)
-			const double xi = sx[ii], yi = sy[ii], zi = sz[ii];
+			const double xi = sx[VPS * ii], yi = sy[VPS * ii], zi = sz[VPS * ii];
 			for (int row = 0; row < 9; ++row) {
 				const int r0 = rowbase + (row / 3) * (RY * RX) + (row % 3) * RX;
 				const uint32_t jb = T.cstart[r0], je = T.cstart[r0 + 3];
 				for (uint32_t j = jb; j < je; ++j)
-					if (j != ii) v_pair<true>(xi, yi, zi, sx[j], sy[j], sz[j], rc2, eps24, sig2, acc);
+					if (j != ii) v_pair<true>(xi, yi, zi, sx[VPS * j], sy[VPS * j], sz[VPS * j], rc2, eps24, sig2, acc);
 			}
 		} else if (active) {
 			// shell does not fit the staging area (pathological density): same arithmetic straight from global memory
@@ -519,9 +529,9 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 				}
 				double x0, y0, z0;
 				if (staged) {  // (a select between an LDS and a global pointer would become flat loads)
-					x0 = sx[ii];
-					y0 = sy[ii];
-					z0 = sz[ii];
+					x0 = sx[VPS * ii];
+					y0 = sy[VPS * ii];
+					z0 = sz[VPS * ii];
 				} else {
 					x0 = P.x[gi];
 					y0 = P.y[gi];
@@ -663,25 +673,25 @@ __device__ __forceinline__ void stage_positions(const ForceParams& P, const Bric
 #pragma unroll
 		for (int h = 0; h < 2; ++h)
 			if (sdst[j][h] != 0xffffffffu) {
-				sx[sdst[j][h]] = px[j][h];
-				sy[sdst[j][h]] = py[j][h];
-				sz[sdst[j][h]] = pz[j][h];
+				sx[VPS * sdst[j][h]] = px[j][h];
+				sy[VPS * sdst[j][h]] = py[j][h];
+				sz[VPS * sdst[j][h]] = pz[j][h];
 			}
 	if (more) {  // cells with more than 32 molecules (dense clusters): the rest in a plain loop
 		for (int c = tid >> 4; c < VNRC; c += VNT / 16) {
 			const uint32_t n = T.cstart[c + 1] - T.cstart[c], s0 = T.cstart[c], g0 = T.gbeg[c];
 			for (uint32_t k = 32u + sub; k < n; k += 16u) {
-				sx[s0 + k] = P.x[g0 + k];
-				sy[s0 + k] = P.y[g0 + k];
-				sz[s0 + k] = P.z[g0 + k];
+				sx[VPS * (s0 + k)] = P.x[g0 + k];
+				sy[VPS * (s0 + k)] = P.y[g0 + k];
+				sz[VPS * (s0 + k)] = P.z[g0 + k];
 			}
 		}
 	}
 	const uint32_t total = total_of();  // (evaluated here: behind the position loads and their stores)
 	if (tid < 8) {
-		sx[total + tid] = VFAR;
-		sy[total + tid] = VFAR;
-		sz[total + tid] = VFAR;
+		sx[VPS * (total + tid)] = VFAR;
+		sy[VPS * (total + tid)] = VFAR;
+		sz[VPS * (total + tid)] = VFAR;
 	}
 }
 
@@ -791,7 +801,7 @@ __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int n
 		fpos[3 * (total + tid) + 2] = 1.0e18f;
 	}
 	__syncthreads();
-	const uint64_t dummy = (uint64_t)(total * 8u) * 0x0001000100010001ull;  // four entries pointing at the far-away slot
+	const uint64_t dummy = (uint64_t)(total * (uint32_t)VES) * 0x0001000100010001ull;  // four entries pointing at the far-away slot
 	const float ext = (float)fmax(fmax(RX * P.g.clen[0], RY * P.g.clen[1]), VRZ * P.g.clen[2]);
 	const float rcs = (float)sqrt(P.vl_rc2);
 	const float thr = (float)P.vl_rc2 * (1.0f + 1e-5f) + 2e-6f * ext * rcs;
@@ -887,7 +897,7 @@ __global__ void __launch_bounds__(VNT, 4) k_lj_verlet_build(ForceParams P, int n
 					while (m) {
 						const uint32_t b = (uint32_t)__builtin_clz(m);
 						m &= ~(0x80000000u >> b);
-						put_hit((jblk + b) * 8u);
+						put_hit((jblk + b) * (uint32_t)VES);
 					}
 				}
 			};
@@ -928,8 +938,8 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet(ForceParams P, int n
 	constexpr int CAPS = VCAPS;
 	__shared__ double spos[3 * CAPS];
 	double* const sx = spos;
-	double* const sy = spos + CAPS;
-	double* const sz = spos + 2 * CAPS;
+	double* const sy = spos + VCO;
+	double* const sz = spos + 2 * VCO;
 	__shared__ uint32_t cstart[VNRC + 1];
 	__shared__ uint32_t gbeg[VNRC];
 	__shared__ uint32_t bstart[VNBC + 1];
@@ -1048,8 +1058,8 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet_sp(ForceParams P, in
 	constexpr int CAPS = VCAPS, NT = VNT, NW = VNW;
 	__shared__ float fpos[3 * CAPS];
 	float* const fx = fpos;
-	float* const fy = fpos + CAPS;
-	float* const fz = fpos + 2 * CAPS;
+	float* const fy = fpos + VCO;
+	float* const fz = fpos + 2 * VCO;
 	__shared__ double red[VNW][4];
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const BrickSel bs = brick_select<1, VBX, VBY, VBZ>(P, nbx, nby, nbz);
@@ -1107,24 +1117,24 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet_sp(ForceParams P, in
 #pragma unroll
 			for (int h = 0; h < 2; ++h)
 				if (sdst[j][h] != 0xffffffffu) {
-					fx[sdst[j][h]] = (float)(px[j][h] - ox);
-					fy[sdst[j][h]] = (float)(py[j][h] - oy);
-					fz[sdst[j][h]] = (float)(pz[j][h] - oz);
+					fx[VPS * sdst[j][h]] = (float)(px[j][h] - ox);
+					fy[VPS * sdst[j][h]] = (float)(py[j][h] - oy);
+					fz[VPS * sdst[j][h]] = (float)(pz[j][h] - oz);
 				}
 		if (more) {
 			for (int c = tid >> 4; c < VNRC; c += NT / 16) {
 				const uint32_t s0 = rec[c], n = rec[c + 1] - s0, g0 = rec[VREC_GBEG + c];
 				for (uint32_t k = 32u + sub; k < n; k += 16u) {
-					fpos[3 * (s0 + k)] = (float)(P.x[g0 + k] - ox);
-					fpos[3 * (s0 + k) + 1] = (float)(P.y[g0 + k] - oy);
-					fpos[3 * (s0 + k) + 2] = (float)(P.z[g0 + k] - oz);
+					fx[VPS * (s0 + k)] = (float)(P.x[g0 + k] - ox);
+					fy[VPS * (s0 + k)] = (float)(P.y[g0 + k] - oy);
+					fz[VPS * (s0 + k)] = (float)(P.z[g0 + k] - oz);
 				}
 			}
 		}
 		if (tid < 8) {
-			fx[total + tid] = 1.0e15f;  // far-away dummy slot (r^2 ~ 1e30: fails every cutoff test)
-			fy[total + tid] = 1.0e15f;
-			fz[total + tid] = 1.0e15f;
+			fx[VPS * (total + tid)] = 1.0e15f;  // far-away dummy slot (r^2 ~ 1e30: fails every cutoff test)
+			fy[VPS * (total + tid)] = 1.0e15f;
+			fz[VPS * (total + tid)] = 1.0e15f;
 		}
 	}
 	__syncthreads();
@@ -1149,7 +1159,7 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet_sp(ForceParams P, in
 			vx0 = P.vx[gi]; vy0 = P.vy[gi]; vz0 = P.vz[gi];
 		}
 		const uint32_t nw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pass == 0 ? head.nw : (uint32_t)P.vl_nw[tile_g]));
-		const f32x2 xi = {fx[ii], fx[ii]}, yi = {fy[ii], fy[ii]}, zi = {fz[ii], fz[ii]};
+		const f32x2 xi = {fx[VPS * ii], fx[VPS * ii]}, yi = {fy[VPS * ii], fy[VPS * ii]}, zi = {fz[VPS * ii], fz[VPS * ii]};
 		const uint64_t* const wp = P.vl_words + tile_g * VMAXW * 64 + lane;
 		const uint32_t last = nw - 1u;
 		uint64_t r0 = head.w0, r1 = head.w1;
@@ -1166,11 +1176,11 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet_sp(ForceParams P, in
 			// entries are byte offsets of the FP64 layout (8 j): halved for the FP32 arrays
 			const uint32_t o0 = (lo32 & 0xffffu) >> 1, o1 = lo32 >> 17, o2 = (hi32 & 0xffffu) >> 1, o3 = hi32 >> 17;
 			const f32x2 xa = {*reinterpret_cast<const float*>(fxb + o0), *reinterpret_cast<const float*>(fxb + o1)};
-			const f32x2 ya = {*reinterpret_cast<const float*>(fxb + o0 + CAPS * 4), *reinterpret_cast<const float*>(fxb + o1 + CAPS * 4)};
-			const f32x2 za = {*reinterpret_cast<const float*>(fxb + o0 + 2 * CAPS * 4), *reinterpret_cast<const float*>(fxb + o1 + 2 * CAPS * 4)};
+			const f32x2 ya = {*reinterpret_cast<const float*>(fxb + o0 + VCO * 4), *reinterpret_cast<const float*>(fxb + o1 + VCO * 4)};
+			const f32x2 za = {*reinterpret_cast<const float*>(fxb + o0 + 2 * VCO * 4), *reinterpret_cast<const float*>(fxb + o1 + 2 * VCO * 4)};
 			const f32x2 xb = {*reinterpret_cast<const float*>(fxb + o2), *reinterpret_cast<const float*>(fxb + o3)};
-			const f32x2 yb = {*reinterpret_cast<const float*>(fxb + o2 + CAPS * 4), *reinterpret_cast<const float*>(fxb + o3 + CAPS * 4)};
-			const f32x2 zb = {*reinterpret_cast<const float*>(fxb + o2 + 2 * CAPS * 4), *reinterpret_cast<const float*>(fxb + o3 + 2 * CAPS * 4)};
+			const f32x2 yb = {*reinterpret_cast<const float*>(fxb + o2 + VCO * 4), *reinterpret_cast<const float*>(fxb + o3 + VCO * 4)};
+			const f32x2 zb = {*reinterpret_cast<const float*>(fxb + o2 + 2 * VCO * 4), *reinterpret_cast<const float*>(fxb + o3 + 2 * VCO * 4)};
 			if (DPACC) {
 				SAcc2 w = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 				sp_pair2<SHIFT>(xi, yi, zi, xa, ya, za, rc2, sig2, w, nin);

@@ -344,3 +344,41 @@ def test_local_rebuild_criterion_with_fast_outliers():
         assert rel_max(b[3], a[3]) < 1e-9, mode
         for k in ("upot", "virial", "summv2"):
             assert abs(a[4][k] - b[4][k]) <= 1e-10 * abs(a[4][k]), (mode, k)
+
+
+@pytest.mark.parametrize("precision,tol", [(0, 1e-11), (1, 3e-5), (2, 6e-5)])
+def test_list_pass_with_a_crowded_cell_in_a_regular_brick(precision, tol):
+    """A cell with more than 32 molecules inside a brick that is otherwise REGULAR (region fits the staging area, every list fits):
+    the staging's second loop (molecules 33... of a cell) of the FP64 and of the single-precision list kernels.  Dilute soft gas
+    (8 molecules per cell) + 27 extra molecules in one cell; against the generic per-step kernel."""
+    rng = np.random.default_rng(11)
+    L = 22.4  # 8 cells of 2.8 = rc + skin 0.3: 2 x 2 x 4 bricks
+    h = np.arange(0.7, L, 1.4)
+    gas = np.stack(np.meshgrid(h, h, h, indexing="ij"), -1).reshape(-1, 3) + rng.uniform(-0.3, 0.3, (len(h) ** 3, 3))
+    c = 2.8 * 3 + 0.6 + 0.8 * np.arange(3)
+    blob = np.stack(np.meshgrid(c, c, c, indexing="ij"), -1).reshape(-1, 3) + rng.uniform(-0.1, 0.1, (27, 3))
+    r = np.concatenate([gas, blob]) % L
+    n = len(r)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    v = np.zeros_like(r)
+    soft = inp.ComponentSet([inp.make_component(lj=[(0, 0, 0, 1, 1e-3, 0.3, 2.5, 0)])], np.zeros((0, 2)), 1e10)
+    in_cell = np.all((r >= 8.4) & (r < 11.2), axis=1).sum()
+    assert in_cell > 32, in_cell
+    ref = _engine(soft, 2.5, [L] * 3, ids, r, v, force_kernel=capi.FK_GENERIC)
+    u0, w0 = ref.forces(0)
+    F0 = _state(ref)[3]
+    ref.close()
+    e = engine_mod.DeviceEngine(0)
+    e.set_components(soft, 2.5)
+    e.set_option("precision", precision)
+    e.set_verlet(0.3)  # not forced: the regions fit
+    e.set_domain([L] * 3)
+    e.upload(ids, np.zeros(n, np.int32), r, v)
+    assert e.get_option("verlet_lists") == 1
+    assert e.update() is True
+    u, w = e.forces_list(0, 0.0, want_macro=True)
+    assert e.get_option("verlet_irregular_bricks") == 0 and e.get_option("precision_in_use") == precision
+    F = _state(e)[3]
+    assert rel_max(F, F0) < tol
+    assert abs(u - u0) <= 10 * tol * abs(u0) and abs(w - w0) <= 10 * tol * abs(w0)
+    e.close()

@@ -113,15 +113,31 @@ void DomainDecompHip::exchange(ls1hip_ctx* ctx, const double globalLength[3], in
 		}
 		if (_impl->mailbox) {
 			if (!_impl->exMailbox) _impl->exMailbox.reset(new HaloExchangerT<MailboxTransport>(dc, ctx, *_impl->mailbox));
-			_impl->exMailbox->exchange(kind);
+			if (kind == 2) _impl->exMailbox->exchange_refresh();
+			else _impl->exMailbox->exchange(kind);
 		} else {
 			if (!_impl->exRccl) _impl->exRccl.reset(new HaloExchangerT<RcclTransport>(dc, ctx, *_impl->rccl));
-			_impl->exRccl->exchange(kind);
+			if (kind == 2) _impl->exRccl->exchange_refresh();
+			else _impl->exRccl->exchange(kind);
 		}
 	} catch (const std::exception& e) {
 		global_log->error() << "DomainDecompHip: exchange of kind " << kind << " failed: " << e.what() << std::endl;
 		Simulation::exit(693);
 	}
+}
+
+// a rebuild moves molecules between ranks: all ranks rebuild, or none
+bool DomainDecompHip::anyRank(bool mine) {
+	if (_world == 1) return mine;
+	double v = mine ? 1. : 0.;
+	try {
+		if (_impl->mailbox) _impl->mailbox->all_reduce(&v, 1, ReduceOp::Max);
+		else _impl->rccl->all_reduce(&v, 1, ReduceOp::Max);
+	} catch (const std::exception& e) {
+		global_log->error() << "DomainDecompHip: rebuild decision: " << e.what() << std::endl;
+		Simulation::exit(695);
+	}
+	return v > 0.;
 }
 
 // LinkedCells::update has classified the molecules (ls1hip_rebin: leavers packed per direction); here they travel, then the

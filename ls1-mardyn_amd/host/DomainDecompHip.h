@@ -63,6 +63,8 @@ public:
 	int localDevice() const { return _device; }
 	void neighbourTable(const double globalLength[3], int nbr[27]);                      // neighbor_rank[27] of ls1hip_set_domain
 	void exchange(ls1hip_ctx* ctx, const double globalLength[3], int kind);              // 0 leaving molecules, 1 halo copies
+	// kind 2 = the position refresh of a list-reuse step (the records of the last halo exchange, 3 doubles each, no count exchange)
+	bool anyRank(bool mine);                                                             // logical OR over the ranks (rebuild decision)
 
 private:
 	struct Impl;

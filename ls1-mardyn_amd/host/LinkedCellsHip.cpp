@@ -244,7 +244,7 @@ void LinkedCellsHip::uploadFromMirror() {
 	_skin = 0.08 * sim->getcutoffRadius();
 	if (const char* e = getenv("LS1HIP_SKIN")) _skin = atof(e);
 	if (mirror().getHaloWidthNumCells() != 1) _skin = 0.;
-	if (_multiRank) _skin = 0.;  // the multi-rank seam of the driver searches every step (the list-mode exchange is the handed-over loop's)
+	if (_multiRank && getenv("LS1HIP_MULTIRANK_LISTS") && atoi(getenv("LS1HIP_MULTIRANK_LISTS")) == 0) _skin = 0.;  // (search every step)
 	if ((rc = ls1hip_set_verlet(_ctx, _skin > 0. ? 1 : 0, _skin))) die("ls1hip_set_verlet", rc);
 	double glen[3], bmin[3], bmax[3];
 	int nbr[27];
@@ -297,9 +297,30 @@ void LinkedCellsHip::update() {
 		uploadFromMirror();
 	}
 	if (_multiRank) {
-		// classification only (leavers packed per direction); DomainDecompHip::balanceAndExchange moves them, then the halo copies
-		int rc = ls1hip_rebin(_ctx);
-		if (rc) die("ls1hip_rebin", rc);
+		// List mode (the piecewise scheme of ls1hip.h "list mode", as the handed-over decomposed loop runs it): between two rebuilds
+		// no molecule changes its owner and every halo copy keeps its slot — this step only refreshes positions (see
+		// exchangeAcrossRanks).  The ranks rebuild together: each polls its displacement bound (advanced on the device by the
+		// integrator's drift), one logical OR over the ranks decides.
+		long ready = 0;
+		ls1hip_get_option(_ctx, "verlet_ready", &ready);
+		bool rebuild = true;
+		if (_skin > 0. && ready) {
+			long pending = 0;
+			ls1hip_get_option(_ctx, "verlet_bound_pending", &pending);
+			int need = 0;
+			if (pending) {  // (no drift since the lists were built or last asked: they are still good)
+				int rcp = ls1hip_verlet_poll(_ctx, &need);
+				if (rcp) die("ls1hip_verlet_poll", rcp);
+			}
+			rebuild = need != 0;
+		}
+		DomainDecompHip* dd = dynamic_cast<DomainDecompHip*>(&global_simulation->domainDecomposition());
+		_rebuildStep = dd ? dd->anyRank(rebuild) : rebuild;
+		if (_rebuildStep) {
+			// classification only (leavers packed per direction); DomainDecompHip::balanceAndExchange moves them, then the halo copies
+			int rc = ls1hip_rebin(_ctx);
+			if (rc) die("ls1hip_rebin", rc);
+		}
 		_inExchange = true;
 		return;
 	}
@@ -314,10 +335,18 @@ void LinkedCellsHip::update() {
 void LinkedCellsHip::exchangeAcrossRanks(DomainDecompHip& dd, Domain* domain) {
 	double glen[3];
 	for (int d = 0; d < 3; ++d) glen[d] = domain->getGlobalLength(d);
+	int rc;
+	if (!_rebuildStep) {  // list-reuse step: current positions of the build-time halo records, nothing else travels
+		if ((rc = ls1hip_halo_refresh(_ctx))) die("ls1hip_halo_refresh", rc);
+		dd.exchange(_ctx, glen, 2);
+		return;
+	}
 	dd.exchange(_ctx, glen, 0);
-	int rc = ls1hip_halo(_ctx);
-	if (rc) die("ls1hip_halo", rc);
+	if ((rc = ls1hip_halo(_ctx))) die("ls1hip_halo", rc);
 	dd.exchange(_ctx, glen, 1);
+	long lists = 0;
+	ls1hip_get_option(_ctx, "verlet_lists", &lists);
+	if (lists && (rc = ls1hip_verlet_build(_ctx))) die("ls1hip_verlet_build", rc);
 }
 
 void LinkedCellsHip::updateMoleculeCaches() {

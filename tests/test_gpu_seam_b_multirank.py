@@ -27,11 +27,12 @@ from test_gpu_seam_b import HIPB, _restart_records
 pytestmark = pytest.mark.gpu
 
 
-def _launch_ranks(world, cfg_dir_of_rank, steps, comm_dir):
+def _launch_ranks(world, cfg_dir_of_rank, steps, comm_dir, extra_env=None):
     procs = []
     for r in range(world):
         env = dict(os.environ, OMP_NUM_THREADS="2", RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", LS1HIP_DEVICE="0",
                    LS1HIP_TRANSPORT="mailbox", LS1HIP_COMM_DIR=comm_dir)
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([HIPB, "config.xml", "--steps", str(steps), "--final-checkpoint=1"], cwd=cfg_dir_of_rank[r],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
@@ -49,9 +50,11 @@ def _launch_ranks(world, cfg_dir_of_rank, steps, comm_dir):
 
 
 @pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(HIPB)), reason="oracle/_ref binaries not built")
-@pytest.mark.parametrize("world", [2, 4])
-def test_reference_driver_decomposed_over_ranks(tmp_path, world):
-    steps = 12
+# lists: the multi-rank seam in LIST MODE (round 3: between two rebuilds only positions travel, the ranks decide a rebuild together);
+# skin 0.06 makes the 16-step run rebuild several times, the default skin (0.08 r_c) outlives it; "0" = search every step
+@pytest.mark.parametrize("world,lists", [(2, "0.06"), (4, "0.06"), (2, "default"), (2, "0")])
+def test_reference_driver_decomposed_over_ranks(tmp_path, world, lists):
+    steps = 16
     src = os.path.join(GOLDEN, "inputs", "synthetic_bcc1clj_20.inp.gz")  # 16 000 molecules, L = 27.3 sigma
     with gzip.open(src, "rb") as fi, open(tmp_path / "bcc.inp", "wb") as fo:
         shutil.copyfileobj(fi, fo)
@@ -79,11 +82,20 @@ def test_reference_driver_decomposed_over_ranks(tmp_path, world):
         dirs.append(str(d))
     comm = tempfile.mkdtemp(prefix="ls1hip_comm_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
-        outs = _launch_ranks(world, dirs, steps, comm)
+        outs = _launch_ranks(world, dirs, steps, comm, {} if lists == "default" else {"LS1HIP_SKIN": lists})
     finally:
         shutil.rmtree(comm, ignore_errors=True)
     log0 = outs[0][1]
     assert f"DomainDecompHip: rank 0 of {world}" in log0 and "transport mailbox" in log0
+    m = re.search(r"neighbour lists (on|off): (\d+) builds for (\d+)", log0)
+    assert m, log0[-2000:]
+    if lists == "0":
+        assert m.group(1) == "off"
+    else:
+        builds, evals = int(m.group(2)), int(m.group(3))
+        assert m.group(1) == "on" and evals == steps + 1 and 1 <= builds < evals, (builds, evals)
+        if lists == "0.06":
+            assert builds >= 3, builds
     rows = re.findall(r"Simstep = (\d+)\s+T = (\S+)\s+U_pot = (\S+)\s+p = (\S+)", log0)
     hip_rows = np.array([[float(x) for x in r[1:]] for r in rows])
     assert len(hip_rows) >= steps

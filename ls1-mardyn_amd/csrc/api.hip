@@ -996,8 +996,14 @@ static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
 	const double ncell = (double)c->g.box[0] * c->g.box[1] * c->g.box[2];
 	const double mean_per_cell = ncell > 0 ? (double)c->n_real / ncell : 0.;
 	// local rebuild criterion (kernels_force_verlet.hip, k_bound_local): complete fused traversals of a single periodic domain
-	const bool local_crit = fp.vl && fuse && which == 0 && !c->has_remote && c->opt_local_rebuild && c->d_vl_top2;
-	if (local_crit) P.vl_top2 = c->d_vl_top2;
+	const bool local_ok = fp.vl && c->one_clj && which == 0 && !c->has_remote && c->opt_local_rebuild && c->d_vl_top2;
+	const bool local_crit = local_ok && fuse;
+	// A pass that does the post-force kick but leaves the drift to a separate kick + drift pass (NVT; piecewise drivers) reports,
+	// per brick, the two largest BOUNDS of the coming drift speed: |beta v + dt/2m F| <= max(beta, 1) (|v| + |dt/2m F|), the
+	// thermostat factor beta being known only after this pass.  track_unfused_drift turns them into the local criterion.
+	const bool local_post = local_ok && !fuse && fp.post_kick;
+	if (local_crit || local_post) P.vl_top2 = c->d_vl_top2;
+	c->vl_top2_pending = local_post;
 	if (fp.vl && !c->one_clj) {
 		if (which != 0) FAIL(c, LS1HIP_EINVAL, "multi-site neighbour lists serve complete traversals (which = 0)");
 		bool lj_only = true;
@@ -1169,9 +1175,15 @@ static IntegArgs integ_args_lists(ls1hip_ctx* c, double dt) {
 	a.vmax_part = c->d_partials;
 	return a;
 }
-static int track_unfused_drift(ls1hip_ctx* c, double dt) {
+// beta: the thermostat factor the drift pass applied to the velocities (host value), or < 0: it took cnt->beta[0] on the device
+static int track_unfused_drift(ls1hip_ctx* c, double dt, double beta = 1.) {
 	const uint32_t nb = ((uint32_t)c->n_real + 255u) / 256u;
-	launch_bound_update(c->d_cnt, c->d_partials, nb, dt, 0.5 * c->vl_skin, c->vl_fresh, ++c->vl_seq, c->d_flag, c->stream);
+	// local criterion (single periodic domain): the force pass before this drift left every brick's two largest drift-speed
+	// bounds (launch_forces, local_post); the global bound then only decides together with the brick neighbourhoods' pair bounds
+	const bool local = c->vl_top2_pending && c->vl_ready && c->one_clj && !c->has_remote && c->opt_local_rebuild && c->d_vl_top2 && c->d_vl_acc;
+	c->vl_top2_pending = false;
+	if (local) launch_bound_local(c->g, c->d_vl_top2, c->d_vl_acc, c->d_cnt, dt, 0.5 * c->vl_skin, c->stream, beta < 0. ? -1. : std::max(beta, 1.));
+	launch_bound_update(c->d_cnt, c->d_partials, nb, dt, 0.5 * c->vl_skin, c->vl_fresh, ++c->vl_seq, c->d_flag, c->stream, local);
 	HIPCHK(c, hipGetLastError());
 	c->vl_fresh = false;
 	c->vl_bound_pending = true;
@@ -1198,7 +1210,7 @@ static int kick_drift_impl(ls1hip_ctx* c, double dt, int pre_scale, double bt, d
 		IntegArgs a = integ_args_lists(c, dt);
 		a.pre_scale = pre_scale; a.pre_bt = bt; a.pre_br = br;
 		launch_kick_drift(a, c->stream);
-		int rcb = track_unfused_drift(c, dt);
+		int rcb = track_unfused_drift(c, dt, pre_scale == 0 ? 1. : pre_scale == 2 ? -1. : bt);
 		if (rcb) return rcb;
 	} else {
 		IntegArgs a = integ_args(c, dt);
@@ -1304,7 +1316,9 @@ extern "C" int ls1hip_scale_kick_drift_components(ls1hip_ctx* c, int ncomp, cons
 	}
 	launch_kick_drift(a, c->stream);
 	if (c->vl_ready) {
-		int rcb = track_unfused_drift(c, dt);
+		double bmax = 1.;
+		for (int k = 0; k < ncomp; ++k) bmax = std::max(bmax, beta_trans[k]);
+		int rcb = track_unfused_drift(c, dt, bmax);
 		if (rcb) return rcb;
 	}
 	HIPCHK(c, hipGetLastError());

@@ -152,6 +152,7 @@ struct ls1hip_ctx {
 	ls1::CompTable h_ct;
 	ls1::CompTable* d_ct = nullptr;
 	double rc = 0, rc_lj = 0;
+	bool vl_top2_pending = false;  // the last force pass left per-brick drift-speed bounds for the coming unfused drift
 	bool one_clj = false;
 	// domain
 	ls1::Grid g;
@@ -350,7 +351,10 @@ int verlet_region_capacity();  // molecules of a brick's region the list kernels
 int verlet_region_cells();
 void verlet_brick_shape(int shape[3]);
 int verlet_record_words();
-void launch_bound_local(const Grid& g, const double* top2, double* acc, DevCounters* cnt, double dt, double limit, hipStream_t s);
+// speed_factor: the speeds in top2 are multiplied by it (1: they are drift speeds; max(beta, 1) for the bounds a post-kick pass left;
+// < 0: max(cnt->beta[0], 1) read on the device)
+void launch_bound_local(const Grid& g, const double* top2, double* acc, DevCounters* cnt, double dt, double limit, hipStream_t s,
+						double speed_factor = 1.);
 long verlet_brick_count(const Grid& g);  // cells per brick edge of the list kernels
 // brick-tiled multi-site kernel (kernels_force_ms.hip); returns false if it cannot handle the configuration
 bool launch_force_ms(const ForceParams& p, bool with_vi, bool has_rot, bool one_component, hipStream_t s, uint32_t* nblocks,
@@ -409,7 +413,7 @@ struct IntegArgs {
 // (the host folds components into thermostats: Leapfrog.cpp:84-104, Domain::getThermostat)
 void launch_kin_by_component(const IntegArgs& a, int ncomp, double* scratch, double* out, hipStream_t s);
 void launch_bound_update(DevCounters* cnt, const double* vmax_part, uint32_t nblocks, double dt, double limit, bool fresh, uint32_t seq,
-						 volatile uint32_t* flag, hipStream_t s);
+						 volatile uint32_t* flag, hipStream_t s, bool local_criterion = false);
 void launch_kick_drift(const IntegArgs& a, hipStream_t s);
 void launch_kick(const IntegArgs& a, hipStream_t s, uint32_t* nblocks);
 void launch_kick_then_kick_drift(const IntegArgs& a, hipStream_t s);

@@ -502,13 +502,22 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 				// next step, which has to wait for the thermostat's scaling factor (NVT) — saves the separate kick pass
 				const double k = P.dt_inv2m;
 				const double vx = vx0 + k * fx, vy = vy0 + k * fy, vz = vz0 + k * fz;
-				tot.kin += P.mass * (vx * vx + vy * vy + vz * vz);
+				const double vv = vx * vx + vy * vy + vz * vz;
+				tot.kin += P.mass * vv;
 				P.vx[gi] = vx;
 				P.vy[gi] = vy;
 				P.vz[gi] = vz;
 				P.Fx[gi] = fx;
 				P.Fy[gi] = fy;
 				P.Fz[gi] = fz;
+				if (P.vl_top2) {
+					// local rebuild criterion of the coming (separate) drift: |beta v + k F| <= max(beta, 1) (|v| + k |F|), and without
+					// square roots (two of them cost 0.2 ms per pass at 10^8): (a + b)^2 <= (1 + e) a^2 + (1 + 1 / e) b^2, e = 1 / 50 —
+					// k |F| is ~1 % of a fast |v|, the bound is 1 % above the speed
+					const double u2 = fma(1.02, vv, (51. * k * k) * (fx * fx + fy * fy + fz * fz));
+					tot.vmax2b = fmax(tot.vmax2b, fmin(tot.vmax2, u2));
+					tot.vmax2 = fmax(tot.vmax2, u2);
+				}
 			} else {
 				// lj_store of kernels_force_lj.hip (upd_postF, then upd_preF of the next step) + the drift speed of this step
 				const double k = P.dt_inv2m;
@@ -587,7 +596,8 @@ __device__ __forceinline__ void store_partials(const ForceParams& P, const Total
 		}
 		out[0] = su;
 		out[1] = sk;  // fused mode: sum m v^2 (see k_force_lj_brick)
-		out[2] = sm;  // fused mode: max |v_drift|^2 of the molecules (combined by max in the reduction)
+		out[2] = P.fuse == 2 ? 0. : sm;  // fused mode: max |v_drift|^2 of the molecules (combined by max in the reduction); a
+		                                 // post-kick pass only feeds vl_top2 (slot 2 is a SUM there: the reaction-field term)
 		out[3] = sv;
 		if (top2) {
 			P.vl_top2[2 * (size_t)brick_id] = sm;
@@ -1221,13 +1231,19 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet_sp(ForceParams P, in
 			} else if (P.fuse == 2) {  // post-force kick only, F kept (see brick_forces)
 				const double k2 = P.dt_inv2m;
 				const double vx = vx0 + k2 * fxd, vy = vy0 + k2 * fyd, vz = vz0 + k2 * fzd;
-				tot.kin += P.mass * (vx * vx + vy * vy + vz * vz);
+				const double vv = vx * vx + vy * vy + vz * vz;
+				tot.kin += P.mass * vv;
 				P.vx[gi] = vx;
 				P.vy[gi] = vy;
 				P.vz[gi] = vz;
 				P.Fx[gi] = fxd;
 				P.Fy[gi] = fyd;
 				P.Fz[gi] = fzd;
+				if (P.vl_top2) {  // bounds for the local rebuild criterion of the coming drift (see brick_forces)
+					const double u2 = fma(1.02, vv, (51. * k2 * k2) * (fxd * fxd + fyd * fyd + fzd * fzd));
+					tot.vmax2b = fmax(tot.vmax2b, fmin(tot.vmax2, u2));
+					tot.vmax2 = fmax(tot.vmax2, u2);
+				}
 			} else {  // the FP64 epilogue of brick_forces
 				const double k2 = P.dt_inv2m;
 				double vx = vx0 + k2 * fxd;
@@ -1265,7 +1281,7 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet_sp(ForceParams P, in
 // 10^8 molecules every step) is the special case s2 = s1 = global maximum: the local one is never earlier, and ~13 % later at
 // T* = 0.95.  Single periodic domain only (a remote rank's halo molecules do not report their speeds here).
 __global__ void __launch_bounds__(256) k_bound_local(int nbx, int nby, int nbz, const double* __restrict__ top2, double* __restrict__ acc,
-												  DevCounters* cnt, double dt, double limit) {
+												  DevCounters* cnt, double dt, double limit, double speed_factor) {
 	const int b = blockIdx.x * 256 + threadIdx.x;
 	if (b >= nbx * nby * nbz) return;
 	const int bx = b % nbx, by = (b / nbx) % nby, bz = b / (nbx * nby);
@@ -1284,18 +1300,22 @@ __global__ void __launch_bounds__(256) k_bound_local(int nbx, int nby, int nbz, 
 			}
 	// acc and vl_base are zeroed by the list build; unfused drifts in between (the first step of a run, NVT steps) add their
 	// dt * v_max to vl_base for every brick
-	const double v = acc[b] + dt * 0.5 * (sqrt(m1) + sqrt(m2));
+	// (unfused drifts: top2 holds bounds of |v| + |dt/2m F| from the pass that did the post-force kick; the drift then moved
+	// the molecules with beta v + dt/2m F, |.| <= max(beta, 1) times that)
+	const double fac = speed_factor < 0. ? fmax(cnt->beta[0], 1.) : speed_factor;
+	const double v = acc[b] + dt * 0.5 * fac * (sqrt(m1) + sqrt(m2));
 	acc[b] = v;
 	if (v + cnt->vl_base > limit) atomicOr(&cnt->vl_local_excess, 1u);
 }
 long verlet_brick_count(const Grid& g) {
 	return (long)((g.box[0] + VBX - 1) / VBX) * ((g.box[1] + VBY - 1) / VBY) * ((g.box[2] + VBZ - 1) / VBZ);
 }
-void launch_bound_local(const Grid& g, const double* top2, double* acc, DevCounters* cnt, double dt, double limit, hipStream_t s) {
+void launch_bound_local(const Grid& g, const double* top2, double* acc, DevCounters* cnt, double dt, double limit, hipStream_t s,
+						double speed_factor) {
 	const int nbx = (g.box[0] + VBX - 1) / VBX, nby = (g.box[1] + VBY - 1) / VBY, nbz = (g.box[2] + VBZ - 1) / VBZ;
 	const long nb = (long)nbx * nby * nbz;
 	if (nb <= 0) return;
-	hipLaunchKernelGGL(k_bound_local, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, nbx, nby, nbz, top2, acc, cnt, dt, limit);
+	hipLaunchKernelGGL(k_bound_local, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, nbx, nby, nbz, top2, acc, cnt, dt, limit, speed_factor);
 }
 
 bool launch_force_verlet(const ForceParams& p_in, hipStream_t s, uint32_t* nblocks, size_t partials_cap, BrickLists* bl) {

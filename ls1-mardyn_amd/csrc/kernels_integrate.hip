@@ -364,7 +364,7 @@ void launch_scale(const IntegArgs& a, double beta_trans, double beta_rot, bool f
 // List mode, unfused drifts: advance the displacement bound by dt * max |v| of this pass and publish the rebuild flag
 // (the fused force passes do the same inside k_force_reduce2).
 __global__ void __launch_bounds__(RTPB) k_bound_update(DevCounters* cnt, const double* vmax_part, uint32_t nblocks, double dt, double limit,
-												  int fresh, uint32_t seq, volatile uint32_t* flag) {
+												  int fresh, uint32_t seq, volatile uint32_t* flag, int local_criterion) {
 	double m = 0.;
 	uint32_t b = threadIdx.x;
 	for (; b + 3u * RTPB < nblocks; b += 4u * RTPB) {
@@ -381,17 +381,27 @@ __global__ void __launch_bounds__(RTPB) k_bound_update(DevCounters* cnt, const d
 		for (int i = 0; i < RTPB / 64; ++i) m = fmax(m, red[i]);
 		const double b = (fresh ? 0. : cnt->vl_bound) + dt * sqrt(m);
 		cnt->vl_bound = b;
-		cnt->vl_base = (fresh ? 0. : cnt->vl_base) + dt * sqrt(m);  // local criterion: unfused drifts count for every brick
+		// a drift WITHOUT per-brick bookkeeping counts with the global speed for every brick; with it (k_bound_local ran just before
+		// this kernel) a brick neighbourhood's pair bound decides — never earlier than the global one
+		bool rebuild = b > limit;
+		if (local_criterion) {
+			if (fresh) cnt->vl_base = 0.;
+			rebuild = rebuild && cnt->vl_local_excess != 0u;
+			cnt->vl_local_excess = 0u;
+		} else {
+			cnt->vl_base = (fresh ? 0. : cnt->vl_base) + dt * sqrt(m);
+		}
 		if (flag) {
 			__threadfence_system();
-			*flag = (seq << 1) | (b > limit ? 1u : 0u);
+			*flag = (seq << 1) | (rebuild ? 1u : 0u);
 			__threadfence_system();
 		}
 	}
 }
 void launch_bound_update(DevCounters* cnt, const double* vmax_part, uint32_t nblocks, double dt, double limit, bool fresh, uint32_t seq,
-						 volatile uint32_t* flag, hipStream_t s) {
-	hipLaunchKernelGGL(k_bound_update, dim3(1), dim3(RTPB), 0, s, cnt, vmax_part, nblocks, dt, limit, fresh ? 1 : 0, seq, flag);
+						 volatile uint32_t* flag, hipStream_t s, bool local_criterion) {
+	hipLaunchKernelGGL(k_bound_update, dim3(1), dim3(RTPB), 0, s, cnt, vmax_part, nblocks, dt, limit, fresh ? 1 : 0, seq, flag,
+					   local_criterion ? 1 : 0);
 }
 
 void launch_kin_reduce(DevCounters* cnt, const double* partials, uint32_t nblocks, hipStream_t s, double target_T, double* log) {

@@ -346,6 +346,42 @@ def test_local_rebuild_criterion_with_fast_outliers():
             assert abs(a[4][k] - b[4][k]) <= 1e-10 * abs(a[4][k]), (mode, k)
 
 
+def test_local_rebuild_criterion_for_unfused_drifts_nvt():
+    """NVT runs (and every piecewise driver: the reference's Simulation::simulate through LinkedCellsHip) drift in a separate
+    kick + drift pass.  Round 3: the list force pass that does the post-force kick reports, per BRICK, the two largest bounds
+    |v| + dt/2m |F| of the coming drift speed (|beta v + dt/2m F| <= max(beta, 1) times that) — the local criterion
+    (k_bound_local) now also serves unfused drifts instead of the global dt * v_max.  Same set-up as above (one molecule at four times the thermal
+    maximum), velocity-scaling thermostat on the device: trajectory of the per-step kernels, fewer builds than the global
+    criterion."""
+    n, dt, steps = 40, 0.002, 63
+    L, ids, r, v = synth.bcc_box(n, temp=0.95)
+    rng = np.random.default_rng(3)
+    fast = rng.choice(len(ids), 1, replace=False)
+    d = rng.normal(size=(1, 3))
+    v = v.copy()
+    v[fast] = 16.0 * d / np.linalg.norm(d, axis=1)[:, None]
+    res, builds = {}, {}
+    for mode, skin, opts in (("step", None, {}), ("local", 0.3, {}), ("global", 0.3, {"local_rebuild": 0})):
+        e = _engine(_lj(), 2.5, [L] * 3, ids, r, v, skin=skin, **opts)
+        e.set_thermostat(True, 0.95)
+        out = e.run(dt, steps)
+        res[mode] = _state(e) + (out,)
+        if skin:
+            builds[mode] = e.get_option("verlet_builds")
+        e.close()
+    assert builds["local"] < builds["global"], builds
+    a = res["step"]
+    for mode in ("local", "global"):
+        b = res[mode]
+        dr = a[1] - b[1]
+        dr -= L * np.round(dr / L)
+        assert np.max(np.abs(dr)) < 1e-10 * L, mode
+        assert rel_max(b[2], a[2]) < 1e-10, mode
+        assert rel_max(b[3], a[3]) < 1e-9, mode
+        for k in ("upot", "virial"):
+            assert abs(a[4][k] - b[4][k]) <= 1e-10 * abs(a[4][k]), (mode, k)
+
+
 @pytest.mark.parametrize("precision,tol", [(0, 1e-11), (1, 3e-5), (2, 6e-5)])
 def test_list_pass_with_a_crowded_cell_in_a_regular_brick(precision, tol):
     """A cell with more than 32 molecules inside a brick that is otherwise REGULAR (region fits the staging area, every list fits):

@@ -265,7 +265,9 @@ int ls1hip_long_range_homogeneous(ls1hip_ctx* ctx, const uint64_t* n_per_compone
  * Precedent in the reference: the Verlet-list containers behind particleContainer/AutoPasContainer.cpp:281-346
  * (verletSkinRadius / verletRebuildFrequency).  enabled = 1: used when the mean population of a brick's region fits the
  * LDS staging area of the list kernels (otherwise ls1hip_run keeps the per-step kernels); 2: always (bricks that do not fit
- * are evaluated from global memory: correct, slow — for tests).  Read-only options "verlet_lists", "verlet_builds", "verlet_steps". */
+ * are evaluated from global memory: correct, slow — for tests).  Read-only options "verlet_lists", "verlet_builds", "verlet_steps",
+ * "verlet_ready" (lists built and alive), "verlet_bound_pending" (a drift since the lists were built / last polled: ls1hip_verlet_poll
+ * may be asked), "verlet_irregular_bricks", "list_kick_available" (ls1hip_forces_list_kick applies). */
 int ls1hip_set_verlet(ls1hip_ctx* ctx, int enabled, double skin);
 
 /* The list mode piecewise — what a transport-driven multi-rank loop calls between two rebuilds (ls1hip_run is the

@@ -244,7 +244,12 @@ void LinkedCellsHip::uploadFromMirror() {
 	_skin = 0.08 * sim->getcutoffRadius();
 	if (const char* e = getenv("LS1HIP_SKIN")) _skin = atof(e);
 	if (mirror().getHaloWidthNumCells() != 1) _skin = 0.;
-	if (_multiRank && getenv("LS1HIP_MULTIRANK_LISTS") && atoi(getenv("LS1HIP_MULTIRANK_LISTS")) == 0) _skin = 0.;  // (search every step)
+	// Multi-rank list mode is opt-in (LS1HIP_MULTIRANK_LISTS=1).  Between two rebuilds a molecule may sit up to skin / 2 outside
+	// its owner's box, where the host mirror — a real LinkedCells with the rank's bounding box — cannot hold it: the steps whose
+	// end state is read through the mirror by construction (the last step, every LS1HIP_MIRROR_SYNC_INTERVAL-th step) are made
+	// rebuild steps by all ranks; any OTHER reader of the mirror (an end-of-step plugin with its own schedule) that meets a
+	// molecule awaiting migration stops the run with an explanation (syncMirrorFromDevice) instead of silently missing it.
+	if (_multiRank && !(getenv("LS1HIP_MULTIRANK_LISTS") && atoi(getenv("LS1HIP_MULTIRANK_LISTS")) != 0)) _skin = 0.;  // search every step
 	if ((rc = ls1hip_set_verlet(_ctx, _skin > 0. ? 1 : 0, _skin))) die("ls1hip_set_verlet", rc);
 	double glen[3], bmin[3], bmax[3];
 	int nbr[27];
@@ -313,6 +318,11 @@ void LinkedCellsHip::update() {
 				if (rcp) die("ls1hip_verlet_poll", rcp);
 			}
 			rebuild = need != 0;
+			// steps whose end state is read through the host mirror: ownership must follow the positions (see the skin's comment)
+			Simulation* sim = global_simulation;
+			long interval = 0;
+			if (const char* e = getenv("LS1HIP_MIRROR_SYNC_INTERVAL")) interval = atol(e);
+			if (sim->getSimulationStep() >= sim->getNumTimesteps() || (interval > 0 && _stepIndex % (unsigned long)interval == 0)) rebuild = true;
 		}
 		DomainDecompHip* dd = dynamic_cast<DomainDecompHip*>(&global_simulation->domainDecomposition());
 		_rebuildStep = dd ? dd->anyRank(rebuild) : rebuild;
@@ -420,6 +430,7 @@ void LinkedCellsHip::traversePartialInnermostCells(CellProcessor& cellProcessor,
 }
 
 void LinkedCellsHip::deviceAdvanced() {
+	++_stepIndex;
 	_stepOpen = true;
 	_quietArmed = false;
 	_betaPending = false;  // (the integrator has just applied the factors on the device)
@@ -457,6 +468,24 @@ void LinkedCellsHip::syncMirrorFromDevice(bool applyPendingBeta) {
 	mirror().clear();
 	std::vector<Molecule> mols;
 	mols.reserve(n);
+	if (_multiRank && _skin > 0.) {
+		// multi-rank list mode: a molecule awaiting migration lies outside this rank's box — the mirror would drop it
+		size_t stray = 0;
+		for (size_t i = 0; i < n; ++i)
+			for (int d = 0; d < 3; ++d)
+				if (r[3 * i + d] < _mirror.getBoundingBoxMin(d) || r[3 * i + d] >= _mirror.getBoundingBoxMax(d)) {
+					++stray;
+					break;
+				}
+		if (stray) {
+			global_log->error() << "LinkedCellsHip: " << stray << " owned molecule(s) lie outside this rank's box (multi-rank list mode: they "
+									"migrate at the next list rebuild) and a reader asked for the host mirror at step "
+								<< global_simulation->getSimulationStep()
+								<< ".  Set LS1HIP_MIRROR_SYNC_INTERVAL to the reader's period (those steps rebuild) or run without "
+									"LS1HIP_MULTIRANK_LISTS." << std::endl;
+			Simulation::exit(696);
+		}
+	}
 	for (size_t i = 0; i < n; ++i) {
 		const double betaTrans = betaT[cid[i]], betaRot = betaR[cid[i]];
 		Molecule m(id[i], &comps[cid[i]], r[3 * i], r[3 * i + 1], r[3 * i + 2], betaTrans * v[3 * i], betaTrans * v[3 * i + 1],

@@ -126,6 +126,7 @@ private:
 	bool _kickQueued = false;   // ... and it has been queued
 	bool _uploaded = false;     // the device holds the molecule set
 	bool _mirrorFresh = true;   // the mirror holds the current molecule set
+	unsigned long _stepIndex = 0;  // steps the integrator has started (eventNewTimestep)
 	bool _rebuildStep = true;   // multi-rank list mode: this step re-bins, migrates and rebuilds the lists (decided by all ranks)
 	bool _hostDirty = true;     // molecules were added / removed through the host interface since the last upload
 	bool _multiRank = false;    // more than one rank: update() only classifies, DomainDecompHip exchanges

@@ -52,9 +52,10 @@ def _launch_ranks(world, cfg_dir_of_rank, steps, comm_dir, extra_env=None):
 @pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(HIPB)), reason="oracle/_ref binaries not built")
 # lists: the multi-rank seam in LIST MODE (round 3: between two rebuilds only positions travel, the ranks decide a rebuild together);
 # skin 0.06 makes the 16-step run rebuild several times, the default skin (0.08 r_c) outlives it; "0" = search every step
-@pytest.mark.parametrize("world,lists", [(2, "0.06"), (4, "0.06"), (2, "default"), (2, "0")])
-def test_reference_driver_decomposed_over_ranks(tmp_path, world, lists):
-    steps = 16
+# the 300-step runs see molecules change ranks (at list rebuilds only); their last step is a rebuild step by construction, so that the
+# final checkpoints hold every molecule with its owner by position
+@pytest.mark.parametrize("world,lists,steps", [(2, "0.06", 16), (2, "0.06", 300), (4, "0.06", 300), (2, "default", 16), (2, "0", 16)])
+def test_reference_driver_decomposed_over_ranks(tmp_path, world, lists, steps):
     src = os.path.join(GOLDEN, "inputs", "synthetic_bcc1clj_20.inp.gz")  # 16 000 molecules, L = 27.3 sigma
     with gzip.open(src, "rb") as fi, open(tmp_path / "bcc.inp", "wb") as fo:
         shutil.copyfileobj(fi, fo)
@@ -82,7 +83,10 @@ def test_reference_driver_decomposed_over_ranks(tmp_path, world, lists):
         dirs.append(str(d))
     comm = tempfile.mkdtemp(prefix="ls1hip_comm_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
-        outs = _launch_ranks(world, dirs, steps, comm, {} if lists == "default" else {"LS1HIP_SKIN": lists})
+        env = {"LS1HIP_MULTIRANK_LISTS": "1"}  # (opt-in: see LinkedCellsHip.cpp on readers of the host mirror between rebuilds)
+        if lists != "default":
+            env["LS1HIP_SKIN"] = lists
+        outs = _launch_ranks(world, dirs, steps, comm, env)
     finally:
         shutil.rmtree(comm, ignore_errors=True)
     log0 = outs[0][1]
@@ -126,4 +130,6 @@ def test_reference_driver_decomposed_over_ranks(tmp_path, world, lists):
     dr -= L * np.round(dr / L)
     assert np.max(np.abs(dr)) < 1e-7 * L
     assert np.max(np.abs(A[:, 3:6] - B[:, 3:6])) < 1e-6 * np.max(np.abs(A[:, 3:6]))
+    if steps >= 300:
+        assert len(set(per_rank)) > 1, per_rank  # molecules have migrated
     print(f"[seam B, {world} ranks] molecules per rank {per_rank}")

@@ -705,7 +705,7 @@ def main():
                   f"build every {args.rebuild_every} traversals, FP64")
         out = {
             "metric": metric,
-            "value": value, "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": ("molecule-force-evaluations/s" if args.workload == "mixed" else "particle-updates/s"), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": {"dp": "f64", "spdp": "f32 pair arithmetic, f64 sums and integration (SPDP mode, not the metric's precision)",
                                            "spsp": "f32 pair arithmetic and sums, f64 integration (SPSP mode, not the metric's precision)"}[args.precision],

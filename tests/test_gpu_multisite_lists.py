@@ -289,3 +289,20 @@ def test_component_wise_thermostat_entry_points():
         e.close()
     for k in ("r", "v", "q", "D"):
         assert rel_max(res[0][k], res[1][k]) < 1e-13, k
+
+
+def test_folded_post_force_kick_is_refused_for_multisite_sets():
+    """ls1hip_forces_list_kick serves the single-centre LJ list pass only: a multi-site set answers with an error (and says so in the
+    read-only option), the caller falls back to ls1hip_forces_list + ls1hip_kick — as LinkedCellsHip does."""
+    name = MULTISITE_FORCE_CASES[0]
+    case = MAN[name]
+    ps = inp.read_inp(input_path(case["input"]))
+    st = sorted_phase_space(ps)
+    e = _engine(ps, st, case["rc"], 0.07 * case["rc"], periodic=bool(case["periodic"]))
+    assert e.update() is True
+    assert e.get_option("list_kick_available") == 0
+    with pytest.raises(capi.Ls1HipError):
+        e.forces_list_kick(0.001)
+    e.forces_list(0, 0.0)  # the context is still usable
+    e.kick(0.001)
+    e.close()

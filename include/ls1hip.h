@@ -107,6 +107,14 @@ int ls1hip_set_components(ls1hip_ctx* ctx, int ncomp, const int* nlj, const int*
 						  const double* lj, const double* ch, const double* dp, const double* qp, const double* mass,
 						  const double* I, const double* mix, double eps_rf, double rc, double rc_lj);
 
+/* Rotational degrees of freedom per component as the reference counts them: Component::getRotationalDegreesOfFreedom
+ * (molecules/Component.cpp:140-167 — from the moments of the SITE masses; the I line of an .inp, io/ASCIIReader.cpp:208-212, or
+ * <momentsofinertia>, Component.cpp:88-97, may override the VALUES of the moments afterwards without changing this count).
+ * Optional: ls1hip_set_components derives the count of non-zero moments of `I`, which is the same number unless such an override
+ * turned a zero moment into a non-zero one.  Only the thermostat's degree-of-freedom sums use it (integrators/Leapfrog.cpp:100,126
+ * -> Domain.cpp:204-240), never the motion.  Call after ls1hip_set_components. */
+int ls1hip_set_rot_dof(ls1hip_ctx* ctx, int ncomp, const int* rot_dof);
+
 /* Read back the derived LJ table ([ncenters][ncenters] each; ncenters = sum nlj) — for parity tests of the
  * parameter derivation.  Any pointer may be NULL. */
 int ls1hip_get_lj_table(const ls1hip_ctx* ctx, int* ncenters, double* eps24, double* sig2, double* shift6);

@@ -30,6 +30,7 @@ SYMBOLS = {
     "ls1hip_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_long)]),
     "ls1hip_set_components": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp,
                                         C.c_double, C.c_double, C.c_double]),
+    "ls1hip_set_rot_dof": (C.c_int, [C.c_void_p, C.c_int, _ip]),
     "ls1hip_get_lj_table": (C.c_int, [C.c_void_p, _ip, _dp, _dp, _dp]),
     "ls1hip_set_domain": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int, _ip]),
     "ls1hip_get_grid": (C.c_int, [C.c_void_p, _ip, _dp, _ip]),

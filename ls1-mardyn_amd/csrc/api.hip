@@ -410,6 +410,23 @@ extern "C" int ls1hip_set_components(ls1hip_ctx* c, int ncomp, const int* nlj, c
 	return LS1HIP_OK;
 }
 
+// Component::getRotationalDegreesOfFreedom per component, where it differs from the count of non-zero principal moments that
+// ls1hip_set_components derives: the reference counts the moments computed from the SITE masses (Component.cpp:140-167), the
+// I line of an .inp / <momentsofinertia> of the XML may then override their values (ASCIIReader.cpp:208-212, Component.cpp:88-97)
+// without changing that count.  Enters the thermostat's degree-of-freedom sums only (Leapfrog.cpp:100,126), never the motion.
+extern "C" int ls1hip_set_rot_dof(ls1hip_ctx* c, int ncomp, const int* rot_dof) {
+	if (!c) return LS1HIP_EINVAL;
+	REQUIRE(c, c->have_comp, "ls1hip_set_components must be called first");
+	REQUIRE(c, rot_dof && ncomp == c->h_ct.ncomp, "one value per component of the current set (%d)", c->h_ct.ncomp);
+	for (int k = 0; k < ncomp; ++k) REQUIRE(c, rot_dof[k] >= 0 && rot_dof[k] <= 3, "rotational degrees of freedom must be in 0..3");
+	for (int k = 0; k < ncomp; ++k) c->h_ct.rotdof[k] = rot_dof[k];
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	HIPCHK(c, hipMemcpyAsync(c->d_ct, &c->h_ct, sizeof(c->h_ct), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return LS1HIP_OK;
+}
+
 extern "C" int ls1hip_get_lj_table(const ls1hip_ctx* c, int* ncenters, double* eps24, double* sig2, double* shift6) {
 	if (!c || !c->have_comp) return LS1HIP_EINVAL;
 	const int n = c->h_ct.ncenters;
@@ -1253,6 +1270,7 @@ extern "C" int ls1hip_kick(ls1hip_ctx* c, double dt_half, double* summv2, double
 	if (!c) return LS1HIP_EINVAL;
 	REQUIRE(c, c->forces_valid, "forces are not valid (call ls1hip_forces)");
 	HIPCHK(c, hipSetDevice(c->device));
+	c->vl_top2_pending = false;  // (a kick after the pass that formed the per-brick bounds: they no longer bound the drift speed)
 	{
 		TimedScope ts(c, c->t_integrate);
 		uint32_t nb = 0;
@@ -1302,6 +1320,7 @@ extern "C" int ls1hip_scale_kick_drift_components(ls1hip_ctx* c, int ncomp, cons
 	REQUIRE(c, c->have_comp && ncomp == c->h_ct.ncomp && beta_trans && beta_rot, "one (beta_trans, beta_rot) pair per component (%d)", c->h_ct.ncomp);
 	REQUIRE(c, c->cap_real, "no molecules uploaded");
 	REQUIRE(c, !c->fused_split, "a fused inner pass is waiting for its boundary pass");
+	REQUIRE(c, !c->pos_x || c->forces_valid, "positions were already advanced by ls1hip_forces_kick_drift (call ls1hip_rebin)");
 	HIPCHK(c, hipSetDevice(c->device));
 	if (c->pos_x && !c->vl_ready) {
 		int rcm = materialise_positions(c);
@@ -1370,6 +1389,9 @@ extern "C" int ls1hip_scale_velocities(ls1hip_ctx* c, double beta_trans, double 
 	if (!c) return LS1HIP_EINVAL;
 	REQUIRE(c, c->cap_real, "no molecules uploaded");
 	HIPCHK(c, hipSetDevice(c->device));
+	// the per-brick drift-speed bounds a post-kick list pass left behind (launch_forces, local_post) were formed from the velocities
+	// of that pass: a scaling in between makes them stale — the coming drift counts with the global bound it measures itself
+	c->vl_top2_pending = false;
 	TimedScope ts(c, c->t_integrate);
 	launch_scale(integ_args(c, 0.), beta_trans, beta_rot, false, c->stream);
 	HIPCHK(c, hipGetLastError());

@@ -58,6 +58,10 @@ class DeviceEngine:
             capi.iptr(keep["nq"]), capi.dptr(keep["lj"]), capi.dptr(keep["ch"]), capi.dptr(keep["dp"]),
             capi.dptr(keep["qp"]), capi.dptr(keep["mass"]), capi.dptr(keep["I"]), capi.dptr(keep["mix"]),
             float(f["eps_rf"]), float(rc), float(rc if rc_lj is None else rc_lj)))
+        rd = np.ascontiguousarray(f["rot_dof"], dtype=np.int32)
+        if not np.array_equal(rd, (np.asarray(f["I"]).reshape(-1, 3) != 0.0).sum(axis=1)):
+            # an I line that overrides a zero site moment: the reference keeps counting the site-derived degrees of freedom
+            self._chk(self.lib.ls1hip_set_rot_dof(self.ctx, int(f["ncomp"]), capi.iptr(rd)))
         self.rc = float(rc)
         self.has_rot = any(c.n_sites > 1 or len(c.dipoles) or len(c.quadrupoles) or
                            np.any(c.lj[:, :3] != 0) or np.any(c.charges[:, :3] != 0) for c in comps.components)

@@ -38,6 +38,11 @@ inline int ls1hip_set_components_from(ls1hip_ctx* ctx, const std::vector<Compone
 	}
 	std::vector<double> mix = domain.getmixcoeff();
 	mix.resize((size_t)nc * (nc - 1), 0.0);  // (xi, eta) per unordered pair
-	return ls1hip_set_components(ctx, nc, nlj.data(), nch.data(), nd.data(), nq.data(), lj.data(), ch.data(), dp.data(), qp.data(),
-								 mass.data(), I.data(), mix.data(), domain.getepsilonRF(), cutoffRadius, LJcutoffRadius);
+	int rc = ls1hip_set_components(ctx, nc, nlj.data(), nch.data(), nd.data(), nq.data(), lj.data(), ch.data(), dp.data(), qp.data(),
+								   mass.data(), I.data(), mix.data(), domain.getepsilonRF(), cutoffRadius, LJcutoffRadius);
+	if (rc) return rc;
+	// the reference's own count of rotational degrees of freedom (from the site masses; an I override does not change it)
+	std::vector<int> rdof(nc);
+	for (int k = 0; k < nc; ++k) rdof[k] = (int)comps[k].getRotationalDegreesOfFreedom();
+	return ls1hip_set_rot_dof(ctx, nc, rdof.data());
 }

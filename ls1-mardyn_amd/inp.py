@@ -62,6 +62,7 @@ class ComponentSet:
             I=np.ascontiguousarray(np.stack([c.I for c in comps]), dtype=np.float64),
             mix=np.ascontiguousarray(self.mix.reshape(-1, 2), dtype=np.float64),
             eps_rf=float(self.eps_rf),
+            rot_dof=np.array([c.rot_dof for c in comps], dtype=np.int32),
         )
 
 
@@ -113,6 +114,10 @@ class PhaseSpace:
     D: np.ndarray  # [n,3] angular momentum
     time: float = 0.0
     temperature: float = 0.0
+    # legacy header thermostats (ASCIIReader.cpp:104-124): target temperature per thermostat id (ThermostatTemperature) and the
+    # thermostat id of a component (ComponentThermostat, 0-based component -> id); empty = one global thermostat (id 0)
+    thermostat_T: dict = dataclasses.field(default_factory=dict)
+    comp_thermostat: dict = dataclasses.field(default_factory=dict)
 
 
 def read_inp(path: str) -> PhaseSpace:
@@ -145,6 +150,8 @@ def read_inp(path: str) -> PhaseSpace:
     comps: List[Component] = []
     mix = np.zeros((0, 2))
     eps_rf = 0.0
+    thermostat_T: dict = {}
+    comp_thermostat: dict = {}
     while True:
         t = nxt()
         if t in ("currentTime", "t"):
@@ -152,9 +159,13 @@ def read_inp(path: str) -> PhaseSpace:
         elif t in ("Temperature", "T"):
             temperature = float(nxt())
         elif t in ("ThermostatTemperature", "ThT", "h"):
-            nxt(); nxt()
+            th = int(nxt())
+            thermostat_T[th] = float(nxt())
         elif t in ("ComponentThermostat", "CT", "o"):
-            nxt(); nxt()
+            c1 = int(nxt())
+            th = int(nxt())
+            if th >= 0:  # ASCIIReader.cpp:121-124 (component ids are 1-based in the file)
+                comp_thermostat[c1 - 1] = th
         elif t in ("Undirected", "U"):
             nxt()
         elif t in ("Length", "L"):
@@ -229,7 +240,7 @@ def read_inp(path: str) -> PhaseSpace:
     return PhaseSpace(
         ComponentSet(comps, mix, eps_rf), length, ids, cid,
         np.ascontiguousarray(r), np.ascontiguousarray(v), np.ascontiguousarray(q), np.ascontiguousarray(D),
-        time, temperature,
+        time, temperature, thermostat_T, comp_thermostat,
     )
 
 
@@ -239,9 +250,13 @@ def write_inp(path: str, ps: PhaseSpace, lj_rows=None) -> None:
     (rc_shift/do_shift are not recoverable from the shift6 we store); default writes unshifted centres."""
     with open(path, "w") as fh:
         fh.write("mardyn trunk 20120726\n")
-        fh.write(f"currentTime\t{ps.time!r}\n")
-        fh.write(f"Length\t{ps.length[0]!r} {ps.length[1]!r} {ps.length[2]!r}\n")
-        fh.write(f"Temperature\t{ps.temperature!r}\n")
+        fh.write(f"currentTime\t{float(ps.time)!r}\n")
+        fh.write(f"Length\t{float(ps.length[0])!r} {float(ps.length[1])!r} {float(ps.length[2])!r}\n")
+        fh.write(f"Temperature\t{float(ps.temperature)!r}\n")
+        for th, T in sorted(ps.thermostat_T.items()):
+            fh.write(f"ThermostatTemperature\t{int(th)} {float(T)!r}\n")
+        for c0, th in sorted(ps.comp_thermostat.items()):
+            fh.write(f"ComponentThermostat\t{c0 + 1} {th}\n")
         comps = ps.components.components
         fh.write(f"NumberOfComponents\t{len(comps)}\n")
         for k, c in enumerate(comps):
@@ -257,13 +272,52 @@ def write_inp(path: str, ps: PhaseSpace, lj_rows=None) -> None:
                     fh.write(" ".join(repr(float(x)) for x in s) + "\n")
             fh.write(" ".join(repr(float(x)) for x in c.I) + "\n")
         for m in ps.components.mix:
-            fh.write(f"{m[0]!r} {m[1]!r}\n")
-        fh.write(f"{ps.components.eps_rf!r}\n")
+            fh.write(f"{float(m[0])!r} {float(m[1])!r}\n")
+        fh.write(f"{float(ps.components.eps_rf)!r}\n")
         n = len(ps.ids)
         fh.write(f"NumberOfMolecules\t{n}\nMoleculeFormat\tICRVQD\n")
         for i in range(n):
             vals = list(ps.r[i]) + list(ps.v[i]) + list(ps.q[i]) + list(ps.D[i])
             fh.write(f"{int(ps.ids[i])}\t{int(ps.cid[i]) + 1}\t" + " ".join(repr(float(x)) for x in vals) + "\n")
+
+
+def components_xml(cs: ComponentSet, names=None) -> str:
+    """The `<components>` body of the reference's XML config for a component set — the inverse of Component::readXML
+    (/root/reference/src/molecules/Component.cpp:32-101; site tags: molecules/Site.h:47-51,112-116,177-179,298-312,360-374)
+    plus one Lorentz-Berthelot `<mixing><rule>` per unordered pair in reader order (ensemble/EnsembleBase.cpp:44-86).  Lets the
+    unmodified driver run the same set from a binary checkpoint (which carries no component block)."""
+    f = lambda x: repr(float(x))  # noqa: E731
+    out = []
+    for k, c in enumerate(cs.components):
+        out.append(f'<moleculetype id="{k + 1}" name="{names[k] if names else "c" + str(k + 1)}">')
+        sid = 0
+        for s in c.lj:
+            sid += 1
+            if s[6] != 0.0:
+                raise ValueError("components_xml: shifted LJ centres are written by the .inp path only")
+            out.append(f'<site type="LJ126" id="{sid}"><coords><x>{f(s[0])}</x><y>{f(s[1])}</y><z>{f(s[2])}</z></coords><mass>{f(s[3])}</mass>'
+                       f'<sigma>{f(s[5])}</sigma><epsilon>{f(s[4])}</epsilon><shifted>0</shifted></site>')
+        for s in c.charges:
+            sid += 1
+            out.append(f'<site type="Charge" id="{sid}"><coords><x>{f(s[0])}</x><y>{f(s[1])}</y><z>{f(s[2])}</z></coords><mass>{f(s[3])}</mass>'
+                       f'<charge>{f(s[4])}</charge></site>')
+        for tab, typ, tag in ((c.dipoles, "Dipole", "dipolemoment"), (c.quadrupoles, "Quadrupole", "quadrupolemoment")):
+            for s in tab:
+                sid += 1
+                out.append(f'<site type="{typ}" id="{sid}"><coords><x>{f(s[0])}</x><y>{f(s[1])}</y><z>{f(s[2])}</z></coords><mass>0</mass>'
+                           f'<{tag}><x>{f(s[3])}</x><y>{f(s[4])}</y><z>{f(s[5])}</z><abs>{f(s[6])}</abs></{tag}></site>')
+        out.append(f'<momentsofinertia rotaxes="xyz"><Ixx>{f(c.I[0])}</Ixx><Iyy>{f(c.I[1])}</Iyy><Izz>{f(c.I[2])}</Izz></momentsofinertia>')
+        out.append('</moleculetype>')
+    n = len(cs.components)
+    if n > 1:
+        out.append('<mixing>')
+        pos = 0
+        for i in range(n):
+            for j in range(i + 1, n):
+                out.append(f'<rule type="LB" cid1="{i + 1}" cid2="{j + 1}"><eta>{f(cs.mix[pos][1])}</eta><xi>{f(cs.mix[pos][0])}</xi></rule>')
+                pos += 1
+        out.append('</mixing>')
+    return "".join(out)
 
 
 # ---- binary checkpoints (SURVEY.md 8f-3) ----------------------------------------------------------------------------

@@ -159,3 +159,89 @@ def bcc_chunks_device(torch, device, n_per_dim: int, lo=None, hi=None, rho: floa
                 ids, r, v = ids[keep], r[keep], v[keep]
             if ids.numel():
                 yield ids.contiguous(), r.contiguous(), v.contiguous()
+
+
+# ---- the five-component LJ + charge + dipole + quadrupole set (BASELINE configs[4]) ----------------------------------------
+# Sites of /root/reference/test_input/VectorizationMultiComponentMultiPotentials.inp:6-31.  That fixture is a static force test:
+# its first two components consist of dipole / quadrupole sites only, which carry no mass in the reference (Component.cpp:
+# 175-205 "massless"), so neither the reference nor anything else can integrate it (dt / 2m = inf); its third component is a
+# 0.42 u point charge without a repulsive core, and it omits the mixing block.  The INTEGRABLE form used for trajectories and
+# for the particle-updates/s bench keeps every site of the fixture and gives components 1-3 a rigid frame of three
+# Lennard-Jones centres as mass carrier and repulsive core (a bent triatomic like the fixture's own water: centre of mass at
+# the origin, axes = principal axes, three non-zero moments FROM THE SITE MASSES, so that the reference's count of rotational
+# degrees of freedom, Component.cpp:140-167, is the physical one: asymmetric tops turned by dipole / quadrupole torques),
+# writes the mixing block (xi = eta = 1) and eps_RF = 1e10.  Components 4 and 5 (linear LJ + charge + dipole + quadrupole
+# rotor; water) are the fixture's.  LJ parameters of the frame: the fixture's own (component 4's centre) for the heavy site.
+MIXED5_RC = 35.0
+MIXED5_TEMPERATURE = 0.000855040543                      # the fixture's
+MIXED5_NUMBER_DENSITY = 250.0 / 134.266123 ** 3          # the fixture's
+_FRAME = [(0.0, 0.3, 0.0, 0.012, 0.00042, 6.7, 0.0, 0),      # x y z m eps sigma rc_shift do_shift
+          (1.2, -0.9, 0.0, 0.002, 0.0001, 3.0, 0.0, 0),
+          (-1.2, -0.9, 0.0, 0.002, 0.0001, 3.0, 0.0, 0)]
+
+
+def mixed5_components(inp):
+    """ComponentSet of the integrable five-component set (see above); `inp` = the ls1-mardyn_amd.inp module."""
+    mk = inp.make_component
+    comps = [
+        mk(lj=_FRAME, dipoles=[(-2.0, 0, 0, 1, 0, 0, -7.1)]),
+        # (axis normalised: the .inp reader keeps the vector as written — the fixture's (0, 1, 1) — while Component::readXML
+        #  normalises it, Site.h:305-312; a unit vector means the same molecule through either reader)
+        mk(lj=_FRAME, dipoles=[(-2.0, 0, 0, 0, np.sqrt(0.5), np.sqrt(0.5), -1.1)], quadrupoles=[(-2.0, 0, 0, 0, 0, 1, -1.3)]),
+        mk(lj=_FRAME, charges=[(0, 0, 1.0, 0.00042, 0.5)], quadrupoles=[(-2.0, 0, 0, 0, 0, 1, -1.3)]),
+        mk(lj=[(0, 0, -1.0, 0.02, 0.00042, 6.7, 0, 0)], charges=[(0, 0, 1.0, 0.00042, 0.5)], dipoles=[(0, 0, -2.0, 0, 0, 1, 0.9)],
+           quadrupoles=[(-2.0, 0, 0, 0, 0, 1, -1.3)]),
+        mk(lj=[(0, 0.123891518, 0, 0.016, 0.000246810271, 5.95953717, 0, 0)],
+           charges=[(0, -0.159567514, 0, 0, -1.04), (1.43042933, -0.983266012, 0, 0.001008, 0.52),
+                    (-1.43042933, -0.983266012, 0, 0.001008, 0.52)],
+           I_file=(0.00219467882, 0.00412499417, 0.00631967299)),
+    ]
+    return inp.ComponentSet(comps, np.ones((10, 2)), 1e10)
+
+
+def thermal_box(inp, cs, n_per_dim: int, number_density: float, temp: float, jitter_frac: float = 0.2):
+    """PhaseSpace: 2 n^3 molecules of the component set `cs` on a jittered bcc lattice, component = (id - 1) mod ncomp,
+    orientation / velocity / angular momentum drawn from splitmix64 hashes of the molecule id (Maxwell at `temp`:
+    v ~ sqrt(T / m), D_k ~ sqrt(I_k T); D_k = 0 where I_k = 0)."""
+    n = n_per_dim
+    N = 2 * n ** 3
+    L = (N / number_density) ** (1.0 / 3.0)
+    a = L / n
+    idx = np.arange(n ** 3, dtype=np.int64)
+    ix, iy, iz = idx % n, (idx // n) % n, idx // (n * n)
+    base = np.stack([ix, iy, iz], axis=1).astype(np.float64) * a
+    r = np.concatenate([base + 0.25 * a, base + 0.75 * a], axis=0)
+    ids = np.arange(1, N + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        u = [_unit_np(_splitmix_np(ids * np.uint64(32) + np.uint64(k))) for k in range(23)]
+    r = np.mod(r + jitter_frac * a * (np.stack(u[0:3], axis=1) - 0.5), L)
+    r[r >= L] = 0.0
+
+    def normals(k0, cnt):  # Box-Muller, one normal per pair of uniforms
+        out = []
+        for k in range(cnt):
+            m = np.sqrt(-2.0 * np.log(1.0 - u[k0 + 2 * k]))
+            out.append(m * np.cos(2.0 * np.pi * u[k0 + 2 * k + 1]))
+        return np.stack(out, axis=1)
+
+    q = normals(3, 4)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    cid = ((ids - np.uint64(1)) % np.uint64(len(cs.components))).astype(np.int32)
+    mass = np.array([c.mass for c in cs.components])[cid]
+    I = np.stack([c.I for c in cs.components])[cid]
+    v = normals(11, 3) * np.sqrt(temp / mass)[:, None]
+    v -= v.mean(axis=0)
+    # angular momentum: Maxwell in the BODY frame (L_k ~ sqrt(I_k T)), turned into the lab frame the reference stores it in
+    # (D = q.rotate(L_body), Quaternion.cpp:43-62; FullMolecule.cpp:341 takes w = I^-1 q.rotateinv(D))
+    Lb = normals(17, 3) * np.sqrt(I * temp)
+    w_, x_, y_, z_ = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    D = np.stack([(w_ * w_ + x_ * x_ - y_ * y_ - z_ * z_) * Lb[:, 0] + 2. * (x_ * y_ - w_ * z_) * Lb[:, 1] + 2. * (w_ * y_ + x_ * z_) * Lb[:, 2],
+                  2. * (w_ * z_ + x_ * y_) * Lb[:, 0] + (w_ * w_ - x_ * x_ + y_ * y_ - z_ * z_) * Lb[:, 1] + 2. * (y_ * z_ - w_ * x_) * Lb[:, 2],
+                  2. * (x_ * z_ - w_ * y_) * Lb[:, 0] + 2. * (w_ * x_ + y_ * z_) * Lb[:, 1] + (w_ * w_ - x_ * x_ - y_ * y_ + z_ * z_) * Lb[:, 2]],
+                 axis=1)
+    return inp.PhaseSpace(cs, np.array([L, L, L]), ids, cid, r, v, q, D, 0.0, temp)
+
+
+def mixed5_box(inp, n_per_dim: int, jitter_frac: float = 0.2, temp: float = MIXED5_TEMPERATURE):
+    """The integrable five-component set at the fixture's number density, see thermal_box."""
+    return thermal_box(inp, mixed5_components(inp), n_per_dim, MIXED5_NUMBER_DENSITY, temp, jitter_frac)

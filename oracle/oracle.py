@@ -136,18 +136,41 @@ class Oracle:
 
     def rot_dof(self, cid):
         """Sum of Component::getRotationalDegreesOfFreedom over the molecules (Leapfrog.cpp:126)."""
-        I = np.asarray(self.flat["I"]).reshape(-1, 3)
-        per_comp = (I != 0.0).sum(axis=1)
+        if "rot_dof" in self.flat:  # Component::_rot_dof: from the site masses, before an I-line override (Component.cpp:140-167)
+            per_comp = np.asarray(self.flat["rot_dof"])
+        else:
+            per_comp = (np.asarray(self.flat["I"]).reshape(-1, 3) != 0.0).sum(axis=1)
         return int(per_comp[np.asarray(cid)].sum())
 
-    def step(self, dt, cid, r, v, q, D, F, M, L, periodic=True, target_T=None):
+    def step(self, dt, cid, r, v, q, D, F, M, L, periodic=True, target_T=None, thermostats=None):
         """One full time step in the reference's order (Simulation.cpp:995-1099): pre-force kick+drift,
-        wrap + halo + forces, post-force kick.  Arrays are updated in place; returns the force dict."""
+        wrap + halo + forces, post-force kick.  Arrays are updated in place; returns the force dict.
+        thermostats = (thermostat_T {id: T}, comp_thermostat {component: id}) selects the component-wise branch."""
         self.upd_preF(dt, cid, r, v, q, D, F, M)
         if periodic:
             r[:] = self.wrap(r, L)
         out = self.forces(r, q, cid, L, periodic)
         F[:] = out["F"]; M[:] = out["M"]
+        if thermostats is not None and thermostats[1]:
+            # Leapfrog::transition2to3, several thermostats (Leapfrog.cpp:84-112): the post-force kick with one set of sums per
+            # thermostat id; Domain::calculateGlobalValues (Domain.cpp:204-240) turns each into its own pair of betas;
+            # VelocityScalingThermostat::apply, component-wise branch (VelocityScalingThermostat.cpp:47-71, directed velocity 0)
+            th_T, comp_th = thermostats
+            cid = np.asarray(cid)
+            th_of = np.array([comp_th.get(int(c), 0) for c in range(int(self.flat["ncomp"]))])[cid]
+            out["summv2"] = out["sumIw2"] = 0.0
+            out["betas"] = {}
+            for th in sorted(set(th_of.tolist())):
+                idx = np.nonzero(th_of == th)[0]
+                vs, qs, Ds, Fs, Ms = (np.ascontiguousarray(a[idx]) for a in (v, q, D, F, M))
+                mv2, iw2 = self.upd_postF(0.5 * dt, cid[idx], vs, qs, Ds, Fs, Ms)
+                bt, br = self.global_betas(mv2, iw2, len(idx), self.rot_dof(cid[idx]), th_T.get(th, 0.0))
+                v[idx] = vs * bt
+                D[idx] = Ds * br
+                out["betas"][th] = (bt, br)
+                out["summv2"] += mv2 * bt * bt  # sums of the state the step leaves behind (after the scaling)
+                out["sumIw2"] += iw2 * br * br
+            return out
         out["summv2"], out["sumIw2"] = self.upd_postF(0.5 * dt, cid, v, q, D, F, M)
         if target_T is not None:
             # VelocityScalingThermostat::apply, global branch (thermostats/VelocityScalingThermostat.cpp:80-96)

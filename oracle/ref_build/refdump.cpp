@@ -14,7 +14,8 @@
 //
 // usage: refdump <file.inp> <cutoff> <periodic 0|1> <out.bin> [--legacy] [--steps N --dt DT] [--nvt]
 //   --nvt: global velocity-scaling thermostat after every step, exactly the sequence of Simulation::simulate
-//          (Simulation.cpp:1099-1131): calculateGlobalValues -> VelocityScalingThermostat::apply (global betas)
+//          (Simulation.cpp:1099-1131): calculateGlobalValues -> VelocityScalingThermostat::apply (global betas; the
+//          component-wise branch when the .inp header assigns thermostats to components: ThermostatTemperature / ComponentThermostat)
 // output (little-endian): magic "LS1GOLD1", u64 N, u64 nsteps, f64 cutoff, f64 dt, f64 L[3],
 //   f64 upot, f64 virial, f64 summv2, f64 sumIw2, then N records sorted by molecule id:
 //   u64 id, u64 cid, f64 r[3], v[3], q[4], D[3], F[3], M[3], Vi[3]
@@ -137,8 +138,23 @@ int main(int argc, char** argv) {
 			if (nvt) {
 				domain->calculateGlobalValues(dd, c, true, 1.0);
 				VelocityScalingThermostat vst;
-				vst.setGlobalBetaTrans(domain->getGlobalBetaTrans());
-				vst.setGlobalBetaRot(domain->getGlobalBetaRot());
+				if (domain->severalThermostats()) {
+					// the component-wise branch of the driver (Simulation.cpp:1112-1126): one (beta_trans, beta_rot) per
+					// thermostat id of the legacy .inp header (ASCIIReader.cpp:104-124), directed velocity 0
+					vst.enableComponentwise();
+					const size_t ncomp = global_simulation->getEnsemble()->getComponents()->size();
+					for (unsigned cid = 0; cid < ncomp; ++cid) {
+						const int th = domain->getThermostat(cid);
+						vst.setBetaTrans(th, domain->getGlobalBetaTrans(th));
+						vst.setBetaRot(th, domain->getGlobalBetaRot(th));
+						double v0[3];
+						for (int d = 0; d < 3; ++d) v0[d] = domain->getThermostatDirectedVelocity(th, d);
+						vst.setVelocity(th, v0);
+					}
+				} else {
+					vst.setGlobalBetaTrans(domain->getGlobalBetaTrans());
+					vst.setGlobalBetaRot(domain->getGlobalBetaRot());
+				}
 				vst.apply(c);
 			}
 		}

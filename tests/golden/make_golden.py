@@ -68,6 +68,21 @@ CASES = [
     ("bcc1clj_8192_spdp_steps10", "synthetic:bcc1clj:16", 2.5, 1, 10, 0.005, 3),
     ("bcc1clj_8192_spsp_steps10", "synthetic:bcc1clj:16", 2.5, 1, 10, 0.005, 4),
     ("bcc1clj_8192", "synthetic:bcc1clj:16", 2.5, 1, 0, 0.0, 0),
+    # round 4: rigid-body trajectories of ASYMMETRIC tops with multipole torques (FullMolecule.cpp:334-389 with three non-zero
+    # moments; rounds 1-3 pinned linear rotors only).  Periodic water (the reference's VectorizationWater.inp, I = (0.0022,
+    # 0.0041, 0.0063)) with a cutoff that holds pairs, NVE (the fixture's own, rotationally very hot state), and the same model with thermal
+    # velocities under the global velocity-scaling thermostat
+    ("water_rc12_steps5", "VectorizationWater.inp", 12.0, 1, 5, 0.02, 0),
+    ("waterT_250_nvt5", "synthetic:water:5", 12.0, 1, 5, 0.02, 2),
+    # the integrable form of the five-component LJ + charge + dipole + quadrupole set (BASELINE configs[4]; synth.mixed5_*:
+    # the fixture's sites + a massive LJ core for the three components the fixture leaves without mass / core, asymmetric
+    # moments through the I line, mixing block written) on a periodic jittered bcc lattice at the fixture's number density
+    ("mixed5_1024", "synthetic:mixed5:8", 35.0, 1, 0, 0.0, 0),
+    ("mixed5_1024_steps5", "synthetic:mixed5:8", 35.0, 1, 5, 0.2, 0),
+    ("mixed5_1024_nvt5", "synthetic:mixed5:8", 35.0, 1, 5, 0.2, 2),
+    # two components, two thermostats assigned by the legacy .inp header (ThermostatTemperature / ComponentThermostat,
+    # ASCIIReader.cpp:104-124): the component-wise branch of VelocityScalingThermostat::apply (Simulation.cpp:1112-1126)
+    ("twotherm_1024_nvt8", "synthetic:twotherm:8", 2.5, 1, 8, 0.004, 5),
 ]
 
 
@@ -98,8 +113,46 @@ def bcc1clj(n_per_dim, rho=0.785302672, jitter=0.1, temp=0.95):
     return L, r, v
 
 
+def _pkg(name):
+    import importlib
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    return importlib.import_module("ls1-mardyn_amd." + name)
+
+
 def write_synth(path, spec):
     _, kind, n = spec.split(":")
+    if kind == "mixed5":
+        inp = _pkg("inp")
+        inp.write_inp(path, _pkg("synth").mixed5_box(inp, int(n)))
+        return
+    if kind == "water":
+        # the water model of the reference's VectorizationWater.inp (component block and density of that fixture: 250 molecules in
+        # 37^3) with THERMAL velocities / angular momenta at the fixture's temperature: the fixture's own state has T_rot = 0.074
+        # against T_trans = 1.7e-5 and a target of 9.4e-4, which sends the reference's thermostat into its explosion heuristics
+        # (Domain.cpp:255-300: per-molecule clamps, outside the scope of the device thermostat)
+        inp = _pkg("inp")
+        fx = inp.read_inp(os.path.join(INPUTS, "VectorizationWater.inp"))
+        inp.write_inp(path, _pkg("synth").thermal_box(inp, fx.components, int(n), len(fx.ids) / float(np.prod(fx.length)), fx.temperature))
+        return
+    if kind == "twotherm":
+        # 1CLJ atoms (thermostat 1, T = 0.8) mixed with 2CLJ dumbbells (thermostat 2, T = 1.1), reduced units, rho* = 0.6
+        inp = _pkg("inp")
+        L, r, v = bcc1clj(int(n), rho=0.6)
+        N = len(r)
+        cs = inp.ComponentSet([inp.make_component(lj=[(0, 0, 0, 1.0, 1.0, 1.0, 0, 0)]),
+                               inp.make_component(lj=[(0, 0, -0.25, 0.5, 0.6, 0.9, 0, 0), (0, 0, 0.25, 0.5, 0.6, 0.9, 0, 0)])],
+                              np.array([[1.0, 1.0]]), 1e10)
+        ids = np.arange(1, N + 1, dtype=np.uint64)
+        cid = (((ids - 1) // 3) % 2).astype(np.int32)
+        u = np.array([[splitmix64(int(i) * 16 + 9 + k) / 2.0 ** 64 - 0.5 for k in range(7)] for i in ids])
+        q = u[:, :4] + 1e-3
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        D = u[:, 4:7] * 0.8 * (cid == 1)[:, None]
+        D[:, 2] = 0.0
+        ps = inp.PhaseSpace(cs, np.array([L, L, L]), ids, cid, r, v, q, D, 0.0, 0.95, {1: 0.8, 2: 1.1}, {0: 1, 1: 2})
+        inp.write_inp(path, ps)
+        return
     assert kind == "bcc1clj"
     L, r, v = bcc1clj(int(n))
     with open(path, "w") as fh:
@@ -144,7 +197,7 @@ def main():
         cmd = [REFDUMP + {3: "_spdp", 4: "_spsp"}.get(legacy, ""), src, repr(rc), str(periodic), out]
         if legacy == 1:
             cmd.append("--legacy")
-        if legacy == 2:
+        if legacy in (2, 5):  # (5: the header of the input assigns thermostats to components -> component-wise branch)
             cmd.append("--nvt")
         if steps:
             cmd += ["--steps", str(steps), "--dt", repr(dt)]

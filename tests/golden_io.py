@@ -15,7 +15,8 @@ REC = np.dtype([("id", "<u8"), ("cid", "<u8"), ("r", "<f8", 3), ("v", "<f8", 3),
 
 def manifest(single_precision=False):
     """Golden cases of MANIFEST.txt.  Column `legacy`: 0 = VectorizedCellProcessor (FP64 build), 1 = LegacyCellProcessor,
-    2 = with the velocity-scaling thermostat, 3 / 4 = the reference built with -DMARDYN_SPDP / -DMARDYN_SPSP (returned only
+    2 = with the velocity-scaling thermostat, 5 = the same with thermostats assigned to components by the header of the input
+    (`componentwise`; the generic NVT tests drive one global thermostat and skip these), 3 / 4 = the reference built with -DMARDYN_SPDP / -DMARDYN_SPSP (returned only
     with single_precision=True: every other test iterates over the FP64 cases and their 1e-10 tolerances)."""
     out = {}
     with open(os.path.join(GOLDEN, "MANIFEST.txt")) as fh:
@@ -27,7 +28,8 @@ def manifest(single_precision=False):
             if bool(prec) != bool(single_precision):
                 continue
             out[name] = dict(name=name, input=inp, rc=float(rc), periodic=int(periodic), steps=int(steps),
-                             dt=float(dt), legacy=int(int(legacy) == 1), nvt=int(int(legacy) == 2), precision=prec)
+                             dt=float(dt), legacy=int(int(legacy) == 1), nvt=int(int(legacy) in (2, 5)),
+                             componentwise=int(int(legacy) == 5), precision=prec)
     return out
 
 

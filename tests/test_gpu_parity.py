@@ -18,7 +18,7 @@ mirror = load_pkg("mirror")
 capi = load_pkg("capi")
 MAN = manifest()
 FORCE_CASES = [k for k, c in MAN.items() if c["steps"] == 0 and not c["legacy"]]
-STEP_CASES = [k for k, c in MAN.items() if c["steps"] > 0]
+STEP_CASES = [k for k, c in MAN.items() if c["steps"] > 0 and not c["componentwise"]]  # (component-wise thermostats: test_gpu_rotors.py)
 TOL = 1e-10
 
 
@@ -149,7 +149,7 @@ def test_trajectory_matches_reference(name):
         assert abs(dom.getLocalSumIw2() * br2 - g["sumIw2"]) / abs(g["sumIw2"]) < 1e-9
 
 
-@pytest.mark.parametrize("name", [k for k, c in MAN.items() if c["nvt"]])
+@pytest.mark.parametrize("name", [k for k, c in MAN.items() if c["nvt"] and not c["componentwise"]])
 def test_device_nvt_loop_matches_reference(name):
     """ls1hip_run with the on-device global velocity-scaling thermostat (no host round trips) vs the reference."""
     case = MAN[name]

@@ -418,3 +418,48 @@ def test_list_pass_with_a_crowded_cell_in_a_regular_brick(precision, tol):
     assert rel_max(F, F0) < tol
     assert abs(u - u0) <= 10 * tol * abs(u0) and abs(w - w0) <= 10 * tol * abs(w0)
     e.close()
+
+
+def test_piecewise_list_loop_with_a_separate_velocity_scaling_between_pass_and_drift():
+    """the documented piecewise sequence ls1hip_forces_list_kick -> ls1hip_scale_velocities(beta > 1) -> ls1hip_kick_drift.
+    The per-brick drift-speed bounds the post-kick list pass leaves for the local rebuild criterion were formed BEFORE the scaling;
+    a scaling in between must not leave them in force (they would under-count every brick's displacement by the factor beta and
+    delay the rebuild).  A fast outlier makes the criterion bite; heating by 5 % per step for a stretch, then cooling; against the
+    per-step search loop over many list lifetimes.  Also: ls1hip_scale_kick_drift_components refuses to drift a second time after
+    a fused pass already advanced the positions (the guard ls1hip_kick_drift has)."""
+    n, dt, steps = 24, 0.002, 70
+    L, ids, r, v = synth.bcc_box(n, temp=0.95)
+    rng = np.random.default_rng(5)
+    d = rng.normal(size=3)
+    v = v.copy()
+    v[rng.integers(len(ids))] = 14.0 * d / np.linalg.norm(d)
+    beta = lambda s: 1.05 if 10 <= s < 30 else (0.97 if 40 <= s < 55 else 1.0)  # noqa: E731
+    a = _engine(_lj(), 2.5, [L] * 3, ids, r, v, skin=None)
+    b = _engine(_lj(), 2.5, [L] * 3, ids, r, v, skin=0.3)
+    assert b.get_option("verlet_lists") == 1
+    rebuilt = 0
+    for s in range(steps):
+        a.kick_drift(dt); a.rebin(); a.halo(); ua = a.forces(0, want_macro=True); a.kick(0.5 * dt, want_sums=False)
+        a.scale_velocities(beta(s))
+        b.kick_drift(dt)
+        rebuilt += b.update()
+        if b.get_option("list_kick_available"):
+            ub = b.forces_list_kick(0.5 * dt, want_macro=True)
+        else:
+            ub = b.forces_list(0, 0.0, want_macro=True); b.kick(0.5 * dt, want_sums=False)
+        b.scale_velocities(beta(s))
+        assert abs(ua[0] - ub[0]) <= 1e-10 * abs(ua[0]) and abs(ua[1] - ub[1]) <= 1e-9 * abs(ua[1]), s
+    assert rebuilt >= 3
+    sa, sb = _state(a), _state(b)
+    dr = sa[1] - sb[1]
+    dr -= L * np.round(dr / L)
+    assert np.max(np.abs(dr)) < 1e-10 * L
+    assert rel_max(sb[2], sa[2]) < 1e-10 and rel_max(sb[3], sa[3]) < 1e-9
+    a.close(); b.close()
+    # the missing guard
+    e = _engine(_lj(), 2.5, [L] * 3, ids, r, v, skin=0.3)
+    e.update()
+    e.forces_list(0, dt, want_macro=False)  # fused: positions already advanced by this pass
+    with pytest.raises(capi.Ls1HipError):
+        e.scale_kick_drift_components([1.0], [1.0], dt)
+    e.close()

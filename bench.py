@@ -153,7 +153,8 @@ def cpu_baseline(n_per_dim=171, steps=10, budget_s=150, workload="lj"):
     oracle/ref_build (AVX2 = the reference's portable vector mode, and -march=x86-64-v4 = its AVX-512 kernels, the
     VECTOR_INSTRUCTIONS=NATIVE class of an AVX-512 host); the faster of the two is reported, the other one next to it.
     Sample (bounded, ~10-30 s of CPU work): lj = configs[1] (N = 2*171^3 from the reference's own CubicGridGenerator);
-    ethane = the reference's equilibrated ethane box replicated 6^3 (binary checkpoint written by inp.write_checkpoint)."""
+    ethane = the reference's equilibrated ethane box replicated 6^3; mixed = the integrable five-component set on a 2*100^3
+    lattice (both from a binary checkpoint written by inp.write_checkpoint, components through inp.components_xml)."""
     cores, share = cpu_share()
     inp = importlib.import_module("ls1-mardyn_amd.inp")
     builds = [("AVX2", os.path.join(ROOT, "oracle", "_ref", "MarDyn")), ("AVX-512 (-march=x86-64-v4)", os.path.join(ROOT, "oracle", "_ref", "MarDyn_avx512"))]
@@ -163,9 +164,19 @@ def cpu_baseline(n_per_dim=171, steps=10, budget_s=150, workload="lj"):
         k = 6
         big = replicate_phase_space(inp, ps, k)
         L = float(big.length[0])
-        cfg = ETHANE_XML.format(dt=ETHANE_DT, steps=steps, temp=repr(ps.temperature), L=repr(L), rc=ETHANE_RC)
-        extra = {"eth.header.xml": lambda path, big=big: inp.write_checkpoint(path[:-len(".header.xml")], big)}
+        cfg = MS_XML.format(dt=ETHANE_DT, steps=steps, temp=repr(float(ps.temperature)), L=repr(L), rc=ETHANE_RC,
+                            components=inp.components_xml(ps.components, ["C2H6"]))
+        extra = {"ms.header.xml": lambda path, big=big: inp.write_checkpoint(path[:-len(".header.xml")], big)}
         what = f"2CLJ ethane, the reference's Ethan_equilibrated box replicated {k}^3 = {len(big.ids)} molecules, rc={ETHANE_RC}"
+    elif workload == "mixed":
+        synth = importlib.import_module("ls1-mardyn_amd.synth")
+        big = synth.mixed5_box(inp, MIXED_CPU_N)
+        L = float(big.length[0])
+        cfg = MS_XML.format(dt=MIXED_DT, steps=steps, temp=repr(float(big.temperature)), L=repr(L), rc=MIXED_RC,
+                            components=inp.components_xml(big.components))
+        extra = {"ms.header.xml": lambda path, big=big: inp.write_checkpoint(path[:-len(".header.xml")], big)}
+        what = (f"five-component LJ + charge + dipole + quadrupole set (synth.mixed5_box: same recipe as the GPU workload), "
+                f"2*{MIXED_CPU_N}^3 = {len(big.ids)} molecules, rc={MIXED_RC}, dt={MIXED_DT}")
     else:
         N = 2 * n_per_dim ** 3
         L = (N / RHO) ** (1.0 / 3.0)
@@ -213,7 +224,9 @@ def cpu_baseline(n_per_dim=171, steps=10, budget_s=150, workload="lj"):
 ETHANE_RC = 32.1254   # cutoff of the reference's own ethane test (tests/golden MANIFEST, VectorizedCellProcessorTest)
 ETHANE_DT = 0.5
 MIXED_RC = 35.0
-ETHANE_XML = """<?xml version='1.0' encoding='UTF-8'?>
+MIXED_DT = 0.0612     # ~2 fs in the reference's unit system (a0, 1000 u, E_h: time unit 32.7 fs; the shipped Argon example uses 0.0667516)
+MIXED_CPU_N = 100     # cpu_baseline sample of the mixed workload: 2 * 100^3 = 2 000 000 molecules
+MS_XML = """<?xml version='1.0' encoding='UTF-8'?>
 <mardyn version="20100525">
   <refunits type="SI"><length unit="nm">0.1</length><mass unit="u">1</mass><energy unit="K">1</energy></refunits>
   <simulation type="MD">
@@ -222,14 +235,8 @@ ETHANE_XML = """<?xml version='1.0' encoding='UTF-8'?>
     <ensemble type="NVT">
       <temperature unit="reduced">{temp}</temperature>
       <domain type="box"><lx>{L}</lx><ly>{L}</ly><lz>{L}</lz></domain>
-      <components>
-        <moleculetype id="1" name="C2H6">
-          <site type="LJ126" id="1"><coords><x>0.0</x><y>0.0</y><z>-2.2157048</z></coords><mass>0.0150347</mass><sigma>6.6140441</sigma><epsilon>0.00042932536</epsilon><shifted>0</shifted></site>
-          <site type="LJ126" id="2"><coords><x>0.0</x><y>0.0</y><z>2.2157048</z></coords><mass>0.0150347</mass><sigma>6.6140441</sigma><epsilon>0.00042932536</epsilon><shifted>0</shifted></site>
-          <momentsofinertia rotaxes="xyz"><Ixx>0.14762114</Ixx><Iyy>0.14762114</Iyy><Izz>0.0</Izz></momentsofinertia>
-        </moleculetype>
-      </components>
-      <phasespacepoint><file type="binary"><header>eth.header.xml</header><data>eth.dat</data></file></phasespacepoint>
+      <components>{components}</components>
+      <phasespacepoint><file type="binary"><header>ms.header.xml</header><data>ms.dat</data></file></phasespacepoint>
     </ensemble>
     <algorithm>
       <parallelisation type="DomainDecomposition"></parallelisation>
@@ -276,25 +283,12 @@ def replicate_phase_space(inp, ps, k):
 
 
 def mixed_box(inp, n):
-    """configs[4]: the five components of VectorizationMultiComponentMultiPotentials.inp on a jittered bcc
-    lattice at the fixture's number density, component = id mod 5, hash quaternions.  Two of the five components carry no
-    mass in the reference's fixture (pure dipole / dipole + quadrupole sites): the set cannot be integrated, by the reference
-    either — this workload is a force-traversal workload."""
-    ps0 = inp.read_inp(_fixture("VectorizationMultiComponentMultiPotentials.inp"))
-    comps = ps0.components
-    rng = np.random.default_rng(11)
-    n0 = 2 * n ** 3
-    rho = 250.0 / 134.266123 ** 3
-    L = (n0 / rho) ** (1.0 / 3.0)
-    a = L / n
-    g = np.arange(n)
-    gpts = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3) * a
-    r = np.concatenate([gpts + 0.25 * a, gpts + 0.75 * a])
-    r = (r + 0.2 * a * rng.uniform(-0.5, 0.5, r.shape)) % L
-    q = rng.normal(size=(n0, 4))
-    q /= np.linalg.norm(q, axis=1)[:, None]
-    cid = (np.arange(n0) % len(comps.components)).astype(np.int32)
-    return comps, L, np.arange(1, n0 + 1, dtype=np.uint64), cid, r, q
+    """configs[4]: the five components of VectorizationMultiComponentMultiPotentials.inp in their INTEGRABLE form
+    (synth.mixed5_components: every site of the fixture; the three components the fixture leaves without mass / repulsive core
+    get a rigid three-centre LJ frame; mixing block written, reaction field on) on a jittered bcc lattice at the fixture's number
+    density, component = (id - 1) mod 5, Maxwell velocities / angular momenta at the fixture's temperature."""
+    ps = importlib.import_module("ls1-mardyn_amd.synth").mixed5_box(inp, n)
+    return ps
 
 
 PMC_TRAFFIC = (("FETCH_SIZE",), ("WRITE_SIZE",))
@@ -417,16 +411,16 @@ def main():
     ap.add_argument("--workload", choices=("lj", "ethane", "mixed"), default="lj",
                     help="lj = the metric's 1CLJ liquid (default); ethane = BASELINE configs[3]: the reference's equilibrated 2CLJ "
                          "ethane box replicated 10^3 = 9 826 000 molecules, full NVE step; mixed = configs[4]: the five-component LJ + "
-                         "charge + dipole + quadrupole set on the 171^3 bcc lattice (10 000 422 molecules), force traversals only "
-                         "(two of its components are massless in the reference's fixture: no integration possible)")
+                         "charge + dipole + quadrupole set in its integrable form (synth.mixed5_components) on the 171^3 bcc lattice "
+                         "(10 000 422 molecules), full NVE step incl. rigid-body integration")
     ap.add_argument("--melt", type=int, default=-1,
                     help="untimed device steps BEFORE the warm-up steps (lj workload: default 200 — the lattice start melts, list "
                          "lengths spread; the timed window is then steady state)")
     ap.add_argument("--long-run", type=int, default=200,
                     help="lj workload, one GPU: steps of the secondary long window after the timed one (0 = none)")
-    ap.add_argument("--rebuild-every", type=int, default=10,
-                    help="mixed workload (static configuration): the lists are rebuilt every this many traversals, the interval the "
-                         "moving workloads measure")
+    ap.add_argument("--no-align", action="store_true",
+                    help="lj workload: do not place the timed window in the list lifetime (default: the melt phase is extended by a few "
+                         "steps so that the K timed steps hold round(K * builds-per-step) list rebuilds, see config.timed_window)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.melt < 0:
@@ -522,9 +516,10 @@ def main():
             comps, rc_ms, L = big.components, ETHANE_RC, float(big.length[0])
             ids_h, cid_h, r_h, v_h, q_h, D_h = big.ids, big.cid, big.r, big.v, big.q, big.D
         else:
-            comps, L, ids_h, cid_h, r_h, q_h = mixed_box(inp, 171)
-            rc_ms = MIXED_RC
-            v_h, D_h = np.zeros_like(r_h), np.zeros_like(r_h)
+            big = mixed_box(inp, int(os.environ.get("LS1_BENCH_MIXED_N", "171")))  # (other sizes: diagnostics only)
+            comps, rc_ms, L = big.components, MIXED_RC, float(big.length[0])
+            big_T = float(big.temperature)
+            ids_h, cid_h, r_h, v_h, q_h, D_h = big.ids, big.cid, big.r, big.v, big.q, big.D
         eng.set_components(comps, rc_ms)
         eng.set_option("force_kernel", args.kernel)
         if args.skin > 0 and args.kernel != 1:
@@ -532,7 +527,7 @@ def main():
         eng.set_domain([L, L, L])
         eng.upload(ids_h, cid_h, r_h, v_h, q_h, D_h)
         N = len(ids_h)
-        del ids_h, cid_h, r_h, v_h, q_h, D_h
+        del ids_h, cid_h, r_h, v_h, q_h, D_h, big
         eng.rebin(); eng.halo(); eng.forces(0)
         sim = None
         n_total = N
@@ -547,26 +542,11 @@ def main():
     if args.precision != "dp":
         (sim.engine if sim is not None else eng).set_option("precision", {"spdp": 1, "spsp": 2}[args.precision])
 
-    step_dt = {"lj": DT, "ethane": ETHANE_DT, "mixed": 0.0}[args.workload]
-    mixed_state = {"since_build": 0}
+    step_dt = {"lj": DT, "ethane": ETHANE_DT, "mixed": MIXED_DT}[args.workload]
 
     def run(k):
         if sim is not None:
             return sim.run(DT, k, fuse=not args.no_fuse, lists=None if os.environ.get("LS1_BENCH_DECOMP_LISTS", "1") != "0" else False)
-        if args.workload == "mixed":
-            # static configuration: a "step" is one complete force traversal with its per-step global values; the lists are
-            # rebuilt (re-bin + halo + build) every --rebuild-every traversals, the rhythm of the moving workloads
-            uw = None
-            for _ in range(k):
-                if eng.get_option("verlet_lists"):
-                    if mixed_state["since_build"] % args.rebuild_every == 0:
-                        eng.rebin(); eng.halo(); eng.verlet_build()
-                    mixed_state["since_build"] += 1
-                    uw = eng.forces_list(0, 0.0, want_macro=(_ == k - 1))
-                else:
-                    eng.rebin(); eng.halo()
-                    uw = eng.forces(0, want_macro=(_ == k - 1))
-            return {"upot": uw[0], "virial": uw[1]} if uw else None
         return eng.run(step_dt, k)
 
     def sync():
@@ -577,6 +557,7 @@ def main():
             torch.cuda.synchronize()
 
     lattice = None
+    melt_tail = None  # (list builds, steps) over the second half of the melt phase: the rebuild rate of the melted liquid
     if args.melt:
         if args.workload == "lj" and not args.pmc_child and args.melt >= 60:
             # secondary figure, for continuity with earlier rounds (which timed the lattice start): 10 + 30 of the melt steps are
@@ -589,11 +570,43 @@ def main():
             lattice = {"steps": 30, "ms_per_step": (time.perf_counter() - t_l) / 30 * 1e3,
                        "note": "steps 11-40 after the jittered-lattice start (what rounds 1-2 quoted); the headline `value` is the "
                                "steady state after the melt phase"}
-            run(args.melt - 40)
+            rest = args.melt - 40
+            run(rest // 2)
+            eb = sim.engine if sim is not None else eng
+            mb0, ms0 = int(eb.get_option("verlet_builds")), int(eb.get_option("verlet_steps"))
+            run(rest - rest // 2)
+            melt_tail = (int(eb.get_option("verlet_builds")) - mb0, int(eb.get_option("verlet_steps")) - ms0)
         else:
             run(args.melt)
-    run(args.warmup)
     e = sim.engine if sim is not None else eng
+    window = None
+    if args.workload == "lj" and world == 1 and sim is None and not args.pmc_child and not args.no_align and melt_tail \
+            and melt_tail[0] >= 3 and e.get_option("verlet_lists"):
+        # Place the K timed steps in the list lifetime.  A rebuild step costs ~3 ordinary steps and comes every P ~ 11 steps, so a
+        # K-step window holds floor or ceil of K / P of them depending on where it starts (1 instead of the expected
+        # 1.8 in the driver's 20 steps = +8 % on `value`).  The melt phase is therefore extended by a few untimed steps: run until
+        # a rebuild has just happened, then on to the phase at which W warm-up steps + K timed steps hold round(K / P) rebuilds.
+        P = melt_tail[1] / melt_tail[0]        # list lifetime in steps (second half of the melt phase)
+        extra = 0
+        b0 = int(e.get_option("verlet_builds"))
+        for _ in range(40):                      # step until a rebuild has just happened (phase 0)
+            run(1)
+            extra += 1
+            if int(e.get_option("verlet_builds")) > b0:
+                break
+        n_target = int(args.steps / P + 0.5)
+        lo_phi, hi_phi = max(n_target * P - args.steps, 0.0), min((n_target + 1) * P - args.steps, P)
+        phi = 0.5 * (lo_phi + hi_phi) if hi_phi > lo_phi else 0.0   # steps since the last rebuild at the START of the timed window
+        # (the rebuild step just run is step 1 of the new lists' life: phase 1 now, phase 1 + pre + W when the timed window starts)
+        pre = int(round(phi - args.warmup - 1)) % max(int(round(P)), 1)
+        if pre:
+            run(pre)
+            extra += pre
+        window = {"aligned": True, "list_lifetime_steps_estimate": P, "rebuilds_expected_in_K_steps": args.steps / P,
+                  "rebuilds_targeted": n_target, "extra_untimed_steps_for_alignment": extra,
+                  "note": "the melt phase was extended so that the K timed steps hold round(K / lifetime) list rebuilds; `value` is "
+                          "still exactly the K timed steps; `steady_state_value` (a 200-step window) is the long-run rate"}
+    run(args.warmup)
     e.timing_reset()
     e.timing_enable(2)  # the timed region carries the HIP-event pairs of the force launches only (roofline.avg_launch_ms)
     sync()
@@ -632,6 +645,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    world_seen, per_rank = world, None
+    if world > 1:
+        import torch.distributed as dist
+        world_seen = dist.get_world_size()   # what the communicator saw (the driver checks it against --gpus)
+        t = torch.zeros(world_seen, dtype=torch.int64, device="cpu" if rehearse else "cuda")
+        t[dist.get_rank()] = int(e.count()[0])
+        dist.all_reduce(t)
+        per_rank = [int(x) for x in t.tolist()]
     integ_ms, _ = e.timing("integrate")
     rebin_ms, _ = e.timing("rebin")
     halo_ms, _ = e.timing("halo")
@@ -648,8 +669,8 @@ def main():
     else:
         # multi-site force pass (48 B + 56 B for the orientation in and the torque out): read r 24 + q 32, write F 24 + M 24
         alg_bytes_total = n_local * MS_FORCE_BYTES_PER_MOLECULE * args.steps
-        # + rigid-body integrator pass: read r v q D F M (152 B), write r v q D (104 B); static traversals (mixed) have none
-        step_bytes_total = n_local * (MS_FORCE_BYTES_PER_MOLECULE + (256.0 if args.workload == "ethane" else 0.0)) * args.steps
+        # + rigid-body integrator pass: read r v q D F M (152 B), write r v q D (104 B)
+        step_bytes_total = n_local * (MS_FORCE_BYTES_PER_MOLECULE + 256.0) * args.steps
     alg_bytes_per_launch = alg_bytes_total / max(force_n, 1)
     traffic = None
     pmc_extra = {}
@@ -671,7 +692,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_live_pmc and not args.decomp:
         tail = ["--n-per-dim", str(n), "--skin", str(args.skin), "--kernel", str(args.kernel), "--cic", str(args.cic),
                 "--split", str(args.split), "--workload", args.workload, "--melt", str(min(args.melt, 40)),
-                "--rebuild-every", str(args.rebuild_every), "--precision", args.precision] + (["--no-fuse"] if args.no_fuse else []) + \
+                "--precision", args.precision] + (["--no-fuse"] if args.no_fuse else []) + \
                (["--nvt"] if args.nvt else [])
         live, what = live_pmc_traffic(tail)
         live_compute, _what2 = live_pmc_compute(tail, force_ms / 1e3 / max(force_n, 1))
@@ -697,15 +718,17 @@ def main():
                   f"re-bin + halo + list build on rebuild steps, site forces + torques, kick) with per-step U_pot / virial / "
                   f"sum mv^2 / sum Iw^2, FP64")
         else:
-            metric = f"molecule-force-evaluations/sec (whole node), N={n_total} five-component LJ+charge+dipole+quadrupole set, rc={MIXED_RC} (BASELINE configs[4])"
-            wl = (f"the five components of VectorizationMultiComponentMultiPotentials.inp (LJ + charge + dipole + quadrupole sites) "
-                  f"on a jittered 171^3 bcc lattice at the fixture's number density, component = id mod 5, N={n_total}, rc={MIXED_RC}; "
-                  f"a step = ONE complete force traversal (forces, torques, U_pot, virial) of the static configuration — two of the "
-                  f"five components are massless in the reference's fixture, the set cannot be integrated — with re-bin + halo + list "
-                  f"build every {args.rebuild_every} traversals, FP64")
+            metric = f"particle-updates/sec (whole node), N={n_total} five-component LJ+charge+dipole+quadrupole set, rc={MIXED_RC} (BASELINE configs[4])"
+            wl = (f"the five components of VectorizationMultiComponentMultiPotentials.inp (LJ + charge + dipole + quadrupole sites) in "
+                  f"their integrable form (synth.mixed5_components: every site of the fixture + a rigid three-centre LJ frame as mass "
+                  f"carrier / repulsive core for the three components the fixture leaves without; mixing block xi = eta = 1, eps_RF = "
+                  f"1e10) on a jittered bcc lattice at the fixture's number density, component = (id - 1) mod 5, N={n_total}, "
+                  f"rc={MIXED_RC}, dt={MIXED_DT}, T={big_T}; NVE full time step (rigid-body kick-drift incl. asymmetric tops, "
+                  f"re-bin + halo + list build on rebuild steps, site forces + torques of all ten site-type pairs, kick) with per-step "
+                  f"U_pot / virial / sum mv^2 / sum Iw^2, FP64, lattice start")
         out = {
             "metric": metric,
-            "value": value, "unit": ("molecule-force-evaluations/s" if args.workload == "mixed" else "particle-updates/s"), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": {"dp": "f64", "spdp": "f32 pair arithmetic, f64 sums and integration (SPDP mode, not the metric's precision)",
                                            "spsp": "f32 pair arithmetic and sums, f64 integration (SPSP mode, not the metric's precision)"}[args.precision],
@@ -746,6 +769,14 @@ def main():
         if long_run:
             long_run["value"] = n_total / (long_run["ms_per_step"] * 1e-3)
             out["long_run"] = long_run
+            # the number to quote: the rate over a window that averages over the list lifetimes
+            out["steady_state_value"] = long_run["value"]
+            out["value_over_steady_state"] = value / long_run["value"]
+            rate = long_run["list_builds"] / long_run["steps"]
+            tw = window or {"aligned": False}
+            tw.update({"rebuilds_in_timed_window": builds_in_window, "rebuilds_expected_at_the_long_run_rate": args.steps * rate,
+                       "long_run_rebuilds_per_step": rate})
+            out["config"]["timed_window"] = tw
         if live_compute is not None:
             out["roofline"]["compute"] = live_compute
         elif pmc_extra:
@@ -758,14 +789,13 @@ def main():
                 comp["fp64_frac"] = comp["fp64_tflops"] / 78.6
             comp.update({k: v for k, v in pmc_extra.items() if k != "fp64_flop_per_launch"})
             out["roofline"]["compute"] = comp
-        if not args.no_cpu_baseline and world == 1 and args.workload != "mixed":
+        if world > 1:
+            out["rccl_world_size"] = world_seen
+            out["config"]["molecules_per_gpu_by_rank"] = per_rank
+            out["config"]["transport"] = "gloo staged through the host (rehearsal)" if rehearse else "RCCL (torch.distributed nccl backend)"
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(workload=args.workload)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-        elif not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = {"value": None, "unit": "molecule-force-evaluations/s", "cores": 0, "kind": "reference",
-                                   "sample": "none: the reference driver cannot run this set (massless components); its force "
-                                             "traversal alone is timed by the reference's own VectorizationTuner, not by MarDyn's "
-                                             "Simulation speed line"}
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or args.decomp:

@@ -63,7 +63,7 @@ int ls1hip_create(int device, ls1hip_ctx** out);
 int ls1hip_destroy(ls1hip_ctx* ctx);
 /* Text of the last error on this context (never NULL).  ctx may be NULL for creation errors. */
 const char* ls1hip_last_error(const ls1hip_ctx* ctx);
-/* Library version / build target string, e.g. "ls1hip 0.1 gfx950". */
+/* Library version / build target string, e.g. "ls1hip 0.1 gfx950" ("... +variant": see option "build_variant"). */
 const char* ls1hip_version(void);
 
 /* Integer options: "force_kernel" (LS1HIP_FK_*), "cells_in_cutoff" (1|2, LinkedCells <cellsInCutoffRadius>,
@@ -71,6 +71,9 @@ const char* ls1hip_version(void);
  * "deterministic" (0|1 canonical in-cell order by molecule id),
  * "count_pairs" (0|1 tally molecule pairs / site interactions inside the cutoff for ls1hip_pair_stats — the
  * counters of adapter/FlopCounter.cpp:20-76; forces then use the generic kernel),
+ * "build_variant" (read only: 0 = the regular library; 1 = the library contains an object built by tools/ab_variant.sh as a
+ *   timing / layout variant of a kernel — such builds may compute WRONG forces by construction and are for same-box A/B timing only;
+ *   ls1hip_version() then ends in "+variant"),
  * "last_force_kernel" (read only: kernel family of the last force launch — LS1HIP_FK_*: 1 generic, 2 single-centre LJ brick
  *   kernels, 3 multi-site brick kernel, 4 multi-site site kernel, 5 neighbour-list force pass; lets callers / tests see a fallback to the generic kernel),
  * "precision" (list force pass of the single-centre LJ path: 0 = FP64 (default), 1 = SPDP, 2 = SPSP — the reference's

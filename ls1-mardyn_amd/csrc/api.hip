@@ -125,7 +125,7 @@ static void free_cells(ls1hip_ctx* c) {
 }
 
 // ---- lifetime ------------------------------------------------------------------------------------------------------
-extern "C" const char* ls1hip_version(void) { return "ls1hip 0.1 gfx950"; }
+extern "C" const char* ls1hip_version(void) { return (&ls1hip_variant_marker != nullptr) ? "ls1hip 0.1 gfx950 +variant" : "ls1hip 0.1 gfx950"; }
 
 extern "C" const char* ls1hip_last_error(const ls1hip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -283,6 +283,7 @@ extern "C" int ls1hip_get_option(const ls1hip_ctx* c, const char* name, long* v)
 	else if (n == "list_kick_available") *v = (c->vl_ready && c->one_clj) ? 1 : 0;
 	else if (n == "verlet_bound_pending") *v = c->vl_bound_pending ? 1 : 0;  // a drift since the last poll / build: ls1hip_verlet_poll may be asked
 	else if (n == "last_force_kernel") *v = c->last_force_kernel;
+	else if (n == "build_variant") *v = (&ls1hip_variant_marker != nullptr) ? 1 : 0;  // 0 = the regular build (no timing-variant object inside)
 	else if (n == "verlet_lists") *v = c->vl_on ? 1 : 0;
 	else if (n == "verlet_ready") *v = c->vl_ready ? 1 : 0;
 	else if (n == "verlet_builds") *v = (long)c->vl_builds;

@@ -17,6 +17,17 @@
 #include "grid.hpp"
 #include "molpair.hpp"
 
+// A library that contains an object compiled as a timing / layout VARIANT (tools/ab_variant.sh: -DLS1_BUILD_VARIANT) carries this
+// symbol; the regular build does not define it anywhere, so the weak reference below resolves to null
+// (ls1hip_get_option "build_variant", ls1hip_version).
+#ifdef LS1_BUILD_VARIANT
+extern "C" __attribute__((weak, visibility("default"))) const int ls1hip_variant_marker = 1;
+#else
+extern "C" {
+extern __attribute__((weak)) const int ls1hip_variant_marker;
+}
+#endif
+
 namespace ls1 {
 
 struct MolSoA {  // one set of state arrays (two sets exist: the rebin gathers from one into the other)

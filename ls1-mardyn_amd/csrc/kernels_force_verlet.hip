@@ -42,6 +42,22 @@
 #include <cstdlib>
 #include <type_traits>
 
+// Timing variants (phase-decomposition builds whose forces are WRONG BY CONSTRUCTION) do not live in this file: the shipped
+// translation unit sees the neutral hooks below; tools/ab_variant.sh compiles with -DLS1_BUILD_VARIANT, which pulls the variant
+// bodies from csrc/variants/verlet_timing_hooks.hpp and marks the library (ls1hip_get_option "build_variant", ls1hip_version).
+#ifdef LS1_BUILD_VARIANT
+#include "variants/verlet_timing_hooks.hpp"
+#else
+#if defined(LS1_NOLOOP_MOCK) || defined(LS1_NOEPI_MOCK) || defined(LS1_NOSTAGE_MOCK) || defined(LS1_POS_AOS)
+#error "variant switches need -DLS1_BUILD_VARIANT (tools/ab_variant.sh): the regular build never carries them"
+#endif
+#define LS1_HOOK_EPILOGUE(P) true
+#define LS1_HOOK_STAGING(P) true
+#define LS1_HOOK_LAST_ROW(nw) ((nw) - 1u)
+#define LS1_HOOK_ROWS(nw) (nw)
+#define LS1_HOOK_FORCE(f, P) (f)
+#endif
+
 namespace ls1 {
 
 constexpr int VBX = 4, VBY = 4, VBZ = 2;
@@ -50,9 +66,7 @@ constexpr int VNW = VNT / 64;
 constexpr int VRX = VBX + 2, VRY = VBY + 2, VRZ = VBZ + 2;
 constexpr int VNRC = VRX * VRY * VRZ;  // 144 region cells
 constexpr int VNBC = VBX * VBY * VBZ;  // 32 brick cells
-#ifdef LS1_N3_MOCK
-constexpr int VCAPJ = 2560;            // TIMING MOCK of brick-internal Newton 3 (tools/ab_variant.sh): room for the LDS force accumulators
-#elif defined(LS1_POS_AOS)
+#if defined(LS1_POS_AOS)
 constexpr int VCAPJ = 2730;            // x y z of a molecule side by side (24 B): a u16 list entry = slot * 24 reaches 2730 slots
 #else
 constexpr int VCAPJ = 2816;            // staged molecules per brick region (67.8 KB of x, y, z)
@@ -167,35 +181,6 @@ __device__ __forceinline__ void v_pair4(double xi, double yi, double zi, const d
 	}
 }
 
-#ifdef LS1_N3_MOCK
-// TIMING MOCK (results are wrong by construction): what brick-internal Newton 3 would cost.  A third of a molecule's list entries
-// disappear (pairs inside the brick are listed by one partner only), and half of the remaining ones return their force to the
-// partner's LDS accumulator with three ds_add_f64.
-__shared__ double g_sacc[3 * 512];
-template <bool COUNT, bool SIG1 = false>
-__device__ __forceinline__ void v_pair_n3(double xi, double yi, double zi, double xj, double yj, double zj, double rc2, double eps24,
-										  double sig2, VAcc& a, uint32_t slot) {
-	const double dx = xi - xj, dy = yi - yj, dz = zi - zj;
-	const double r2 = fma(dz, dz, fma(dy, dy, dx * dx));
-	const bool in = r2 < rc2;
-	const double d = __hiloint2double(in ? __double2hiint(r2) : 0x7E37E43C, __double2loint(r2));
-	const double inv = v_rcp(d);
-	const double lj2 = SIG1 ? inv : sig2 * inv;
-	const double lj6 = lj2 * lj2 * lj2;
-	const double lj12m6 = fma(lj6, lj6, -lj6);
-	const double fac = inv * fma(lj6, lj6, lj12m6);
-	const double fx = fac * dx, fy = fac * dy, fz = fac * dz;
-	a.fx += fx;
-	a.fy += fy;
-	a.fz += fz;
-	unsafeAtomicAdd(&g_sacc[slot], -fx);
-	unsafeAtomicAdd(&g_sacc[slot + 512], -fy);
-	unsafeAtomicAdd(&g_sacc[slot + 1024], -fz);
-	a.slj += lj12m6;
-	if (COUNT) a.nin += in ? 1u : 0u;
-	a.vir = fma(fac, d, a.vir);
-}
-#endif
 
 // the factor 24 eps common to every pair of the molecule
 __device__ __forceinline__ void v_pair_scale(VAcc& a, double eps24) {
@@ -282,15 +267,11 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 		const size_t tile_g = (size_t)brick_id * VMAXT + tile;
 		uint32_t ii = total, gi = 0;
 		int rowbase = 0;
-#ifndef LS1_NO_SPLIT_TAIL
 		// LEFTOVER TILES of a regular brick (the molecules beyond the 512th: a brick of the aligned grid owns 512 on average, so
 		// every second brick has a handful).  One lane per molecule would run a whole pair loop for them on one wave while the
 		// other seven wait: the tile is split instead — 8 / 4 / 2 lanes per molecule, lane (m, s) takes the word rows s, s + S, ...
 		// of molecule m's list, the partial sums are combined across the lanes of a molecule, lane (m, 0) runs the epilogue.
 		const bool split = pass != 0 && fast_ii != nullptr;
-#else
-		const bool split = false;
-#endif
 		uint32_t sp_m = 0, sp_s = 0, sp_lg = 0, sp_nw = 4u;  // molecule and share of this lane, log2 of the lanes per molecule
 		if (split) {
 			const uint32_t wbase = base + (uint32_t)wv * 64u;
@@ -325,11 +306,7 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 		VAcc acc = {0., 0., 0., 0., 0., 0u};
 		// the epilogue's velocity loads are issued before the pair loop (their latency is hidden behind it)
 		double vx0 = 0., vy0 = 0., vz0 = 0.;
-#ifdef LS1_NOEPI_MOCK
-		const bool epi = P.which != 0;  // run-time false in the bench's single-pass traversal: no velocity loads, no stores
-#else
-		const bool epi = true;
-#endif
+		const bool epi = LS1_HOOK_EPILOGUE(P);  // (true; timing variants: csrc/variants/verlet_timing_hooks.hpp)
 		if (active && P.fuse && epi) {
 			vx0 = P.vx[gi];
 			vy0 = P.vy[gi];
@@ -388,15 +365,7 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 			// row register is reloaded right after its content is consumed — ONE loop-carried value per row: with a rotating
 			// window (w0 <- w1 <- w2 <- w3) the compiler sank every load to its use and waited vmcnt(0) on it, i.e. a dependent
 			// HBM round trip per four pairs; a load inside a branch has the same effect (seen in the ISA).
-#if defined(LS1_PASS2_MOCK)
-			const uint32_t last = pass != 0 ? 3u : nw - 1u;
-#elif defined(LS1_NOLOOP_MOCK)
-			const uint32_t last = 3u;
-#elif defined(LS1_N3_MOCK) || defined(LS1_SHORT_MOCK)
-			const uint32_t last = max(4u, (nw * 2u + 2u) / 3u) - 1u;
-#else
-			const uint32_t last = nw - 1u;  // nw >= 4: rows are dummy-padded by the build
-#endif
+			const uint32_t last = LS1_HOOK_LAST_ROW(nw);  // nw - 1 (nw >= 4: rows are dummy-padded by the build)
 			uint64_t r0 = head.w0, r1 = head.w1;  // first tile: loaded ahead by the caller (rows 0 and 1)
 			if (pass != 0) {
 				r0 = load_row(wp);
@@ -414,42 +383,10 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 							 z2 = *reinterpret_cast<const double*>(sxb + o2 + 2 * VCO * 8);
 				const double x3 = *reinterpret_cast<const double*>(sxb + o3), y3 = *reinterpret_cast<const double*>(sxb + o3 + VCO * 8),
 							 z3 = *reinterpret_cast<const double*>(sxb + o3 + 2 * VCO * 8);
-#ifdef LS1_N3_MOCK
-				v_pair_n3<SHIFT, SIG1>(xi, yi, zi, x0, y0, z0, rc2, eps24, sig2, acc, (o0 >> 3) & 511u);
-				v_pair<SHIFT, SIG1>(xi, yi, zi, x1, y1, z1, rc2, eps24, sig2, acc);
-				v_pair_n3<SHIFT, SIG1>(xi, yi, zi, x2, y2, z2, rc2, eps24, sig2, acc, (o2 >> 3) & 511u);
-				v_pair<SHIFT, SIG1>(xi, yi, zi, x3, y3, z3, rc2, eps24, sig2, acc);
-#elif defined(LS1_PAIR1)
-				v_pair<SHIFT, SIG1>(xi, yi, zi, x0, y0, z0, rc2, eps24, sig2, acc);
-				v_pair<SHIFT, SIG1>(xi, yi, zi, x1, y1, z1, rc2, eps24, sig2, acc);
-				v_pair<SHIFT, SIG1>(xi, yi, zi, x2, y2, z2, rc2, eps24, sig2, acc);
-				v_pair<SHIFT, SIG1>(xi, yi, zi, x3, y3, z3, rc2, eps24, sig2, acc);
-#else
 				const double xj[4] = {x0, x1, x2, x3}, yj[4] = {y0, y1, y2, y3}, zj[4] = {z0, z1, z2, z3};
 				v_pair4<SHIFT, SIG1>(xi, yi, zi, xj, yj, zj, rc2, sig2, acc);
-#endif
 			};
-#ifdef LS1_N3_MOCK
-			nw = max(4u, (nw * 2u + 2u) / 3u);
-#endif
-#ifdef LS1_SHORT_MOCK
-			nw = max(4u, (nw * 2u + 2u) / 3u);  // the shorter lists alone (no accumulator traffic)
-#endif
-#ifdef LS1_NOLOOP_MOCK
-			nw = 0;  // everything but the pair loop: staging, list head, epilogue, reductions
-#endif
-#ifdef LS1_PASS2_MOCK
-			if (pass != 0) nw = 4;  // what would a (nearly) free second pass be worth?  (a handful of molecules beyond the 512th)
-#endif
-#ifdef LS1_NOLIST_MOCK
-			for (uint32_t k = 0; k < nw; k += 4) {  // the pair loop without its list traffic (rows 0-3 over and over)
-				four_pairs(r0);
-				if (k + 1 < nw) four_pairs(r1);
-				if (k + 2 < nw) four_pairs(r2);
-				if (k + 3 < nw) four_pairs(r3);
-				r0 += (uint64_t)(k & 0u);  // keep the loop-carried form
-			}
-#else
+			nw = LS1_HOOK_ROWS(nw);  // (nw)
 			for (uint32_t k = 0; k < nw; k += 4) {
 				// rows past the end are clamped to the last row and evaluated as what they are after the clamp: skipped
 				four_pairs(r0);
@@ -461,7 +398,6 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 				if (k + 3 < nw) four_pairs(r3);
 				r3 = load_row(wp + (size_t)min(k + 7u, last) * 64);
 			}
-#endif
 		} else if (active && staged) {
 			// no stored list for this tile (list overflow, or more owned molecules than the list capacity covers)
 			const double xi = sx[VPS * ii], yi = sy[VPS * ii], zi = sz[VPS * ii];
@@ -485,14 +421,7 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 		}
 		if (active && epi) {
 			v_pair_scale(acc, eps24);
-#if defined(LS1_N3_MOCK) || defined(LS1_SHORT_MOCK) || defined(LS1_NOLOOP_MOCK) || defined(LS1_NOLIST_MOCK) || defined(LS1_PASS2_MOCK)
-			// timing mocks evaluate an incomplete pair set: their (finite, wrong) forces are scaled by a run-time zero so that the
-			// molecules keep moving ballistically instead of blowing up
-			const double mz = (double)P.which;  // 0 in the single-pass traversal the bench runs
-			const double fx = acc.fx * mz, fy = acc.fy * mz, fz = acc.fz * mz;
-#else
-			const double fx = acc.fx, fy = acc.fy, fz = acc.fz;
-#endif
+			const double fx = LS1_HOOK_FORCE(acc.fx, P), fy = LS1_HOOK_FORCE(acc.fy, P), fz = LS1_HOOK_FORCE(acc.fz, P);  // (the sums themselves)
 			if (!P.fuse) {
 				P.Fx[gi] = fx;
 				P.Fy[gi] = fy;
@@ -980,15 +909,6 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet(ForceParams P, int n
 	}
 	ListHead head;
 	Totals tot = {0., 0., 0., 0., 0.};
-#ifdef LS1_ONE_WG_MOCK
-	__shared__ double ballast[4096];  // + 32 KB: one workgroup per CU (does the second workgroup of a CU hide anything?)
-	if (P.which == 7) ballast[tid] = 1.;
-#endif
-#ifdef LS1_STAGGER_MOCK
-	// first generation only: the second workgroup of every CU starts half a workgroup life late (anti-phase instead of lockstep)
-	if (blockIdx.x >= 256u && blockIdx.x < 512u)
-		for (int i = 0; i < LS1_STAGGER_MOCK; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
 	uint32_t* const rec = P.vl_rec + (size_t)did * VREC;
 	// the record's three scalars (region total, owned count, flags; uniform addresses = scalar loads).  Forcing them out at the
 	// head (inline asm) and requesting all kernel arguments of the later phases in one batch was measured: no gain (± 0.3 %) —
@@ -1008,10 +928,8 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet(ForceParams P, int n
 		head = load_list_head(P, did, wv, lane);  // list head and own indices: independent of everything staged below
 		ii0 = f_ii[tid];
 		gi0 = f_gi[tid];
-#ifdef LS1_NOSTAGE_MOCK
-		if (P.which != 0)  // run-time false: the staging is skipped
-#endif
-		stage_positions(P, R, sx, sy, sz, TotalOf{rec_total});
+		if (LS1_HOOK_STAGING(P))  // (true)
+			stage_positions(P, R, sx, sy, sz, TotalOf{rec_total});
 	}
 	__syncthreads();
 	if (rec_flags & 1u) {  // uniform per workgroup
@@ -1356,11 +1274,7 @@ bool launch_force_verlet(const ForceParams& p_in, hipStream_t s, uint32_t* nbloc
 	} else {
 		const bool sig1 = p.sig2 == 1.0;  // reduced units: one multiplication less per pair, same bits
 		auto go = [&](auto sh, auto s1) {
-#ifdef LS1_NO_FAST_HEAD
-			const bool fast = false;  // (A/B switch, tools/ab_variant.sh)
-#else
 			const bool fast = p.did_mode == 1;
-#endif
 			if (fast)
 				hipLaunchKernelGGL((k_force_lj_verlet<decltype(sh)::value, decltype(s1)::value, true>), dim3((uint32_t)nb), dim3(VNT), 0, s, p, nbx, nby, nbz, (int)nb);
 			else

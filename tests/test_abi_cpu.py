@@ -58,3 +58,20 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")) or f == "Makefile":
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "ls1_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_shipped_library_is_not_a_timing_variant():
+    """timing variants of the kernels (phase-decomposition builds whose forces are wrong by construction) are compiled
+    only by tools/ab_variant.sh under -DLS1_BUILD_VARIANT, which marks the library.  The shipped libls1hip.so must not carry the
+    marker symbol, its version string must not say "+variant", the production kernel source must hold no mock switch, and the
+    regular Makefile must not be able to set one."""
+    import subprocess
+    lib = capi.load()
+    assert b"variant" not in lib.ls1hip_version()
+    syms = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "ls1hip_variant_marker" not in syms
+    src = open(os.path.join(ROOT, "ls1-mardyn_amd", "csrc", "kernels_force_verlet.hip")).read()
+    body = src.split('#error "variant switches need -DLS1_BUILD_VARIANT', 1)[1]
+    assert "_MOCK" not in body, "a timing mock crept back into the production kernel (they live in csrc/variants/)"
+    mk = open(os.path.join(ROOT, "ls1-mardyn_amd", "Makefile")).read()
+    assert "LS1_BUILD_VARIANT" in mk and "-DLS1_BUILD_VARIANT" not in mk

@@ -313,3 +313,10 @@ def test_production_list_pass_truncated_shifted_potential():
     (u0, w0, F0), (u1, w1, F1) = res["generic"], res["lists"]
     assert rel_max(F1, F0) < 1e-11
     assert abs(u1 - u0) <= 1e-11 * abs(u0) and abs(w1 - w0) <= 1e-11 * abs(w0)
+
+
+def test_library_under_test_is_the_regular_build():
+    """the library these GPU tests load holds no timing-variant object (tools/ab_variant.sh builds; option "build_variant")"""
+    e = engine_mod.DeviceEngine(0)
+    assert e.get_option("build_variant") == 0 and b"variant" not in e.lib.ls1hip_version()
+    e.close()

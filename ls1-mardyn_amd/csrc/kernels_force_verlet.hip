@@ -56,6 +56,10 @@
 #define LS1_HOOK_LAST_ROW(nw) ((nw) - 1u)
 #define LS1_HOOK_ROWS(nw) (nw)
 #define LS1_HOOK_FORCE(f, P) (f)
+#define LS1_HOOK_EARLY_V true
+#define LS1_HOOK_STORE(ptr, val) (*(ptr) = (val))
+#define LS1_HOOK_RECORD_OF(did) (did)
+#define LS1_HOOK_OWN_FROM_LDS true
 #endif
 
 namespace ls1 {
@@ -307,7 +311,7 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 		// the epilogue's velocity loads are issued before the pair loop (their latency is hidden behind it)
 		double vx0 = 0., vy0 = 0., vz0 = 0.;
 		const bool epi = LS1_HOOK_EPILOGUE(P);  // (true; timing variants: csrc/variants/verlet_timing_hooks.hpp)
-		if (active && P.fuse && epi) {
+		if (active && P.fuse && epi && LS1_HOOK_EARLY_V) {
 			vx0 = P.vx[gi];
 			vy0 = P.vy[gi];
 			vz0 = P.vz[gi];
@@ -450,6 +454,11 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 			} else {
 				// lj_store of kernels_force_lj.hip (upd_postF, then upd_preF of the next step) + the drift speed of this step
 				const double k = P.dt_inv2m;
+				if (!LS1_HOOK_EARLY_V) {
+					vx0 = P.vx[gi];
+					vy0 = P.vy[gi];
+					vz0 = P.vz[gi];
+				}
 				double vx = vx0 + k * fx;
 				double vy = vy0 + k * fy;
 				double vz = vz0 + k * fz;
@@ -457,16 +466,16 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 				vx += k * fx;
 				vy += k * fy;
 				vz += k * fz;
-				P.vx[gi] = vx;
-				P.vy[gi] = vy;
-				P.vz[gi] = vz;
+				LS1_HOOK_STORE(&P.vx[gi], vx);
+				LS1_HOOK_STORE(&P.vy[gi], vy);
+				LS1_HOOK_STORE(&P.vz[gi], vz);
 				{
 					const double v2 = vx * vx + vy * vy + vz * vz;
 					tot.vmax2b = fmax(tot.vmax2b, fmin(tot.vmax2, v2));
 					tot.vmax2 = fmax(tot.vmax2, v2);
 				}
 				double x0, y0, z0;
-				if (staged) {  // (a select between an LDS and a global pointer would become flat loads)
+				if (staged && LS1_HOOK_OWN_FROM_LDS) {  // (a select between an LDS and a global pointer would become flat loads)
 					x0 = sx[VPS * ii];
 					y0 = sy[VPS * ii];
 					z0 = sz[VPS * ii];
@@ -475,9 +484,9 @@ __device__ __forceinline__ void brick_forces(const ForceParams& P, const BrickTa
 					y0 = P.y[gi];
 					z0 = P.z[gi];
 				}
-				P.Fx[gi] = x0 + P.dt * vx;
-				P.Fy[gi] = y0 + P.dt * vy;
-				P.Fz[gi] = z0 + P.dt * vz;
+				LS1_HOOK_STORE(&P.Fx[gi], x0 + P.dt * vx);
+				LS1_HOOK_STORE(&P.Fy[gi], y0 + P.dt * vy);
+				LS1_HOOK_STORE(&P.Fz[gi], z0 + P.dt * vz);
 			}
 			// every in-range pair adds eps24 * (lj12 - lj6) + shift6 to 6 U (nin is tallied where the shift is non-zero and in
 			// the fallbacks)
@@ -924,7 +933,8 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet(ForceParams P, int n
 	// (Also requesting list rows 2 and 3 up here was measured: slower — vmcnt completes in order, so the staging then waits for
 	// two more HBM round trips.)
 	{
-		const BrickTab R = {rec, rec + VREC_GBEG, nullptr};
+		uint32_t* const srec = P.vl_rec + (size_t)LS1_HOOK_RECORD_OF(did) * VREC;  // (= rec; the staging descriptors)
+		const BrickTab R = {srec, srec + VREC_GBEG, nullptr};
 		head = load_list_head(P, did, wv, lane);  // list head and own indices: independent of everything staged below
 		ii0 = f_ii[tid];
 		gi0 = f_gi[tid];

@@ -1,6 +1,7 @@
 // DomainDecompHip.cpp — see DomainDecompHip.h.
 #include "DomainDecompHip.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -38,8 +39,9 @@ struct DomainDecompHip::Impl {
 		if (mailbox) mailbox->barrier();
 		else if (rccl) rccl->barrier();
 	}
+	bool loopback = false;
 	CartDecomp& decomp(int world, int rank, const double L[3]) {
-		if (!cart) cart.reset(new CartDecomp(world, rank, L));
+		if (!cart) cart.reset(new CartDecomp(world, rank, L, loopback));
 		return *cart;
 	}
 };
@@ -52,7 +54,12 @@ DomainDecompHip::DomainDecompHip() : DomainDecompBase(), _impl(new Impl) {
 		global_log->error() << "DomainDecompHip: bad rank / world size (" << _rank << " / " << _world << ")" << std::endl;
 		Simulation::exit(690);
 	}
-	if (_world == 1) return;
+	// LS1HIP_LOOPBACK=1 (one rank): the periodic images this rank would make locally travel through the transport instead — all 26
+	// directions are exported, packed, sent to the own rank, received and imported exactly as between GPUs (rehearsal of the
+	// multi-rank seam on one GPU; decomp.py / bench.py --loopback do the same for the handed-over loops)
+	if (const char* e = getenv("LS1HIP_LOOPBACK")) _impl->loopback = atoi(e) != 0 && _world == 1;
+	_decomposed = _world > 1 || _impl->loopback;
+	if (!_decomposed) return;
 	std::string transport = "rccl";
 	if (const char* e = getenv("LS1HIP_TRANSPORT")) transport = e;
 	try {
@@ -60,8 +67,7 @@ DomainDecompHip::DomainDecompHip() : DomainDecompBase(), _impl(new Impl) {
 			const char* dir = getenv("LS1HIP_COMM_DIR");
 			_impl->mailbox.reset(new MailboxTransport(_world, _rank, dir ? dir : ""));
 		} else if (transport == "rccl") {
-			const char* idf = getenv("LS1HIP_RCCL_ID_FILE");
-			_impl->rccl.reset(new RcclTransport(_world, _rank, _device, idf ? idf : "/tmp/ls1hip_rccl_id"));
+			_impl->rccl.reset(new RcclTransport(_world, _rank, _device, _world > 1 ? rccl_id_source_from_env() : std::string()));
 		} else {
 			global_log->error() << "DomainDecompHip: unknown LS1HIP_TRANSPORT '" << transport << "' (rccl | mailbox)" << std::endl;
 			Simulation::exit(691);
@@ -73,7 +79,8 @@ DomainDecompHip::DomainDecompHip() : DomainDecompBase(), _impl(new Impl) {
 	int g[3];
 	CartDecomp::dims_create(_world, g);
 	global_log->info() << "DomainDecompHip: rank " << _rank << " of " << _world << ", grid " << g[0] << " x " << g[1] << " x " << g[2]
-					   << ", transport " << transport << ", device " << _device << std::endl;
+					   << ", transport " << transport << ", device " << _device << (_impl->loopback ? ", LOOPBACK (own images through the transport)" : "")
+					   << std::endl;
 }
 
 DomainDecompHip::~DomainDecompHip() = default;
@@ -126,6 +133,37 @@ void DomainDecompHip::exchange(ls1hip_ctx* ctx, const double globalLength[3], in
 	}
 }
 
+// variable-length all-gather of raw records (the mirror snapshot's migration of molecules that await theirs on the device):
+// every rank's `n` records of `bytes` each -> all of them, rank by rank
+void DomainDecompHip::gatherRecords(const void* mine, size_t n, size_t bytes, std::vector<char>& all, std::vector<size_t>& counts) {
+	counts.assign((size_t)_world, n);
+	all.clear();
+	if (_world == 1) {
+		all.assign(static_cast<const char*>(mine), static_cast<const char*>(mine) + n * bytes);
+		return;
+	}
+	try {
+		uint64_t c = n;
+		std::vector<char> tab;
+		_impl->gather(&c, sizeof(c), tab);
+		size_t mx = 0;
+		for (int r = 0; r < _world; ++r) {
+			uint64_t v;
+			std::memcpy(&v, tab.data() + (size_t)r * sizeof(v), sizeof(v));
+			counts[(size_t)r] = (size_t)v;
+			mx = std::max(mx, (size_t)v);
+		}
+		if (mx == 0) return;
+		std::vector<char> pad(mx * bytes, 0), g;
+		if (n) std::memcpy(pad.data(), mine, n * bytes);
+		_impl->gather(pad.data(), pad.size(), g);
+		for (int r = 0; r < _world; ++r) all.insert(all.end(), g.begin() + (size_t)r * mx * bytes, g.begin() + (size_t)r * mx * bytes + counts[(size_t)r] * bytes);
+	} catch (const std::exception& e) {
+		global_log->error() << "DomainDecompHip: gather of snapshot records: " << e.what() << std::endl;
+		Simulation::exit(697);
+	}
+}
+
 // a rebuild moves molecules between ranks: all ranks rebuild, or none
 bool DomainDecompHip::anyRank(bool mine) {
 	if (_world == 1) return mine;
@@ -144,7 +182,7 @@ bool DomainDecompHip::anyRank(bool mine) {
 // halo copies (NeighbourCommunicationScheme.cpp:115-136: LEAVING_ONLY, then HALO_COPIES)
 void DomainDecompHip::balanceAndExchange(double lastTraversalTime, bool forceRebalancing, ParticleContainer* moleculeContainer,
 										 Domain* domain) {
-	if (_world == 1) {
+	if (!_decomposed) {
 		DomainDecompBase::balanceAndExchange(lastTraversalTime, forceRebalancing, moleculeContainer, domain);
 		return;
 	}
@@ -154,6 +192,10 @@ void DomainDecompHip::balanceAndExchange(double lastTraversalTime, bool forceReb
 		Simulation::exit(694);
 	}
 	cont->exchangeAcrossRanks(*this, domain);
+}
+
+void DomainDecompHip::assertDisjunctivity(ParticleContainer* moleculeContainer) const {
+	if (LinkedCellsHip* cont = dynamic_cast<LinkedCellsHip*>(moleculeContainer)) cont->snapshotForReaders();
 }
 
 // ---- the reference's typed collectives ------------------------------------------------------------------------------------------

@@ -16,7 +16,9 @@
 //                                                        (Domain.cpp:151-181 calculateGlobalValues, generators, thermostats)
 // With one rank it behaves exactly as DomainDecompBase (the sequential periodic boundary is then handled inside the device
 // container).  Environment: LS1HIP_TRANSPORT = rccl (default when every rank has its own GPU) | mailbox (host-staged files in
-// LS1HIP_COMM_DIR: several ranks per GPU, tests); LS1HIP_RCCL_ID_FILE for the ncclUniqueId hand-over.
+// LS1HIP_COMM_DIR: several ranks per GPU, tests).  The ncclUniqueId travels from rank 0 over a TCP rendezvous on the launcher's
+// MASTER_ADDR : MASTER_PORT + 17 (LS1HIP_RCCL_PORT overrides; LS1HIP_RCCL_ID_FILE = a file instead) — per job, nothing left on disk.
+// LS1HIP_LOOPBACK=1 with one rank routes the own periodic images through the transport (rehearsal of the exchange on one GPU).
 #pragma once
 #include <memory>
 #include <string>
@@ -58,6 +60,11 @@ public:
 	void collCommScanSum() override;
 	void collCommBroadcast(int root = 0) override;
 	std::string getName() override { return "DomainDecompHip"; }
+	// Called by EVERY rank at the head of Domain::writeCheckpoint (Domain.cpp:600), before the ranks write their molecules one
+	// after the other (DomainDecompBase::writeMoleculesToFile, DomainDecompBase.cpp:505-541: a rank iterates while the others wait in
+	// a barrier): the collective point at which the device container refills its host mirror for the readers to come (in
+	// multi-rank list mode that snapshot moves records between ranks, LinkedCellsHip::syncMirrorFromDevice).
+	void assertDisjunctivity(ParticleContainer* moleculeContainer) const override;
 
 	// ---- used by LinkedCellsHip ---------------------------------------------------------------------------------------------
 	int localDevice() const { return _device; }
@@ -65,6 +72,9 @@ public:
 	void exchange(ls1hip_ctx* ctx, const double globalLength[3], int kind);              // 0 leaving molecules, 1 halo copies
 	// kind 2 = the position refresh of a list-reuse step (the records of the last halo exchange, 3 doubles each, no count exchange)
 	bool anyRank(bool mine);                                                             // logical OR over the ranks (rebuild decision)
+	bool decomposed() const { return _decomposed; }  // the container's molecules cross rank boundaries through exchange(): > 1 rank, or the 1-rank loopback rehearsal
+	// every rank's n records of `bytes` bytes each -> all records rank by rank (+ per-rank counts); collective
+	void gatherRecords(const void* mine, size_t n, size_t bytes, std::vector<char>& all, std::vector<size_t>& counts);
 
 private:
 	struct Impl;
@@ -81,6 +91,7 @@ private:
 	void allGatherValues(std::vector<std::vector<Value>>& perRank);
 	void combine(int mode, int root);  // 0 sum, 1 min, 2 max, 3 inclusive scan, 4 broadcast
 	int _rank = 0, _world = 1, _device = 0;
+	bool _decomposed = false;
 	std::vector<Value> _values;
 	size_t _getter = 0;
 	std::unique_ptr<Impl> _impl;

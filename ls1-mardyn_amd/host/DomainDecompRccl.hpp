@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <array>
 #include <chrono>
+#include <ctime>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -32,6 +33,7 @@
 #include <thread>
 #include <vector>
 
+#include "IdHandOver.hpp"
 #include "ls1hip.h"
 
 namespace ls1hip {
@@ -132,35 +134,21 @@ enum class ReduceOp { Sum, Max };
 // ---- transport: one RCCL communicator, its own stream --------------------------------------------------------------------
 class RcclTransport {
 public:
-	// id_file: rank 0 writes the ncclUniqueId there, the others wait for it (one node, shared file system); world 1 needs none
-	RcclTransport(int world, int rank, int device, const std::string& id_file) : _world(world), _rank(rank) {
+	// id_source: where rank 0 hands the ncclUniqueId to the others (IdHandOver.hpp: "tcp:<host>:<port>" or a file); world 1 needs none
+	RcclTransport(int world, int rank, int device, const std::string& id_source) : _world(world), _rank(rank) {
 		LS1_HIPCHECK(hipSetDevice(device));
 		int lo = 0, hi = 0;
 		LS1_HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
 		LS1_HIPCHECK(hipStreamCreateWithPriority(&_stream, hipStreamNonBlocking, hi));
 		ncclUniqueId id;
-		if (rank == 0) {
-			LS1_NCCLCHECK(ncclGetUniqueId(&id));
-			if (world > 1) {
-				const std::string tmp = id_file + ".tmp";
-				FILE* f = fopen(tmp.c_str(), "wb");
-				if (!f || fwrite(&id, sizeof(id), 1, f) != 1) throw std::runtime_error("cannot write " + tmp);
-				fclose(f);
-				if (rename(tmp.c_str(), id_file.c_str())) throw std::runtime_error("cannot publish " + id_file);
-			}
-		} else {
-			for (int tries = 0;; ++tries) {
-				FILE* f = fopen(id_file.c_str(), "rb");
-				if (f) {
-					const bool ok = fread(&id, sizeof(id), 1, f) == 1;
-					fclose(f);
-					if (ok) break;
-				}
-				if (tries > 6000) throw std::runtime_error("no ncclUniqueId in " + id_file);
-				std::this_thread::sleep_for(std::chrono::milliseconds(10));
-			}
+		if (rank == 0) LS1_NCCLCHECK(ncclGetUniqueId(&id));
+		std::string id_file;
+		if (world > 1) {
+			if (id_source.rfind("tcp:", 0) != 0) id_file = id_source;
+			hand_over_bytes(world, rank, id_source, &id, sizeof(id));
 		}
 		LS1_NCCLCHECK(ncclCommInitRank(&_comm, world, id, rank));
+		if (rank == 0 && !id_file.empty()) (void)remove(id_file.c_str());  // every rank has read it: the init above is collective
 		LS1_HIPCHECK(hipMalloc(&_d_small, 64 * sizeof(double) * (size_t)std::max(world, 1)));
 		LS1_HIPCHECK(hipHostMalloc(&_h_small, 64 * sizeof(double) * (size_t)std::max(world, 1)));
 	}

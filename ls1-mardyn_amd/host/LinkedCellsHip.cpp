@@ -18,8 +18,11 @@
 //                                          head of the next eventNewTimestep (same position in the sequence of kicks)
 #include "LinkedCellsHip.h"
 
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <map>
+#include <set>
 
 #include "Domain.h"
 #include "Simulation.h"
@@ -27,6 +30,7 @@
 #include "molecules/Molecule.h"
 #include "parallel/DomainDecompBase.h"
 #include "particleContainer/adapter/VectorizedCellProcessor.h"
+#include "plugins/PluginBase.h"
 #include "utils/Logger.h"
 #include "utils/xmlfileUnits.h"
 
@@ -56,9 +60,16 @@ struct ProfScope {
 	}
 	~ProfScope() {
 		if (!g_prof.on) return;
-		auto& e = g_prof.t[name];
-		e.first += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-		e.second++;
+		const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		// iterator() is called by every thread of the driver's parallel regions (LinkedCells.h:245-250): one writer at a time
+#if defined(_OPENMP)
+#pragma omp critical(ls1hip_profile_map)
+#endif
+		{
+			auto& e = g_prof.t[name];
+			e.first += dt;
+			e.second++;
+		}
 	}
 };
 }  // namespace
@@ -223,7 +234,7 @@ void LinkedCellsHip::uploadFromMirror() {
 	// multi-rank: the decomposition the driver constructed must be the device-side one (seam_b_register.h maps it); it supplies
 	// the rank grid, this rank's neighbours and the transport (RCCL over xGMI, or the host-staged mailbox)
 	DomainDecompHip* dd = dynamic_cast<DomainDecompHip*>(&sim->domainDecomposition());
-	_multiRank = sim->domainDecomposition().getNumProcs() > 1;
+	_multiRank = sim->domainDecomposition().getNumProcs() > 1 || (dd && dd->decomposed());  // (decomposed: > 1 rank, or the loopback rehearsal)
 	if (_multiRank && !dd) {
 		global_log->error() << "LinkedCellsHip: a multi-rank run needs DomainDecompHip (seam_b_register.h / INTEGRATION.md)" << std::endl;
 		Simulation::exit(681);
@@ -244,12 +255,12 @@ void LinkedCellsHip::uploadFromMirror() {
 	_skin = 0.08 * sim->getcutoffRadius();
 	if (const char* e = getenv("LS1HIP_SKIN")) _skin = atof(e);
 	if (mirror().getHaloWidthNumCells() != 1) _skin = 0.;
-	// Multi-rank list mode is opt-in (LS1HIP_MULTIRANK_LISTS=1).  Between two rebuilds a molecule may sit up to skin / 2 outside
-	// its owner's box, where the host mirror — a real LinkedCells with the rank's bounding box — cannot hold it: the steps whose
-	// end state is read through the mirror by construction (the last step, every LS1HIP_MIRROR_SYNC_INTERVAL-th step) are made
-	// rebuild steps by all ranks; any OTHER reader of the mirror (an end-of-step plugin with its own schedule) that meets a
-	// molecule awaiting migration stops the run with an explanation (syncMirrorFromDevice) instead of silently missing it.
-	if (_multiRank && !(getenv("LS1HIP_MULTIRANK_LISTS") && atoi(getenv("LS1HIP_MULTIRANK_LISTS")) != 0)) _skin = 0.;  // search every step
+	// Multi-rank runs use the lists too (round 4: the default; LS1HIP_MULTIRANK_LISTS=0 searches every step).  Between two rebuilds a
+	// molecule may sit up to skin / 2 outside its owner's box, where the host mirror — a real LinkedCells with the rank's bounding
+	// box — cannot hold it: a snapshot for a reader of the mirror (syncMirrorFromDevice) therefore hands such molecules to the rank
+	// whose box they are in, for the snapshot only; the device state and the lists are untouched.
+	if (_multiRank && getenv("LS1HIP_MULTIRANK_LISTS") && atoi(getenv("LS1HIP_MULTIRANK_LISTS")) == 0) _skin = 0.;
+	_overlap = !(getenv("LS1HIP_OVERLAP") && atoi(getenv("LS1HIP_OVERLAP")) == 0);
 	if ((rc = ls1hip_set_verlet(_ctx, _skin > 0. ? 1 : 0, _skin))) die("ls1hip_set_verlet", rc);
 	double glen[3], bmin[3], bmax[3];
 	int nbr[27];
@@ -318,11 +329,6 @@ void LinkedCellsHip::update() {
 				if (rcp) die("ls1hip_verlet_poll", rcp);
 			}
 			rebuild = need != 0;
-			// steps whose end state is read through the host mirror: ownership must follow the positions (see the skin's comment)
-			Simulation* sim = global_simulation;
-			long interval = 0;
-			if (const char* e = getenv("LS1HIP_MIRROR_SYNC_INTERVAL")) interval = atol(e);
-			if (sim->getSimulationStep() >= sim->getNumTimesteps() || (interval > 0 && _stepIndex % (unsigned long)interval == 0)) rebuild = true;
 		}
 		DomainDecompHip* dd = dynamic_cast<DomainDecompHip*>(&global_simulation->domainDecomposition());
 		_rebuildStep = dd ? dd->anyRank(rebuild) : rebuild;
@@ -342,21 +348,37 @@ void LinkedCellsHip::update() {
 
 // DomainDecompHip::balanceAndExchange (multi-rank): leaving molecules, halo generation, halo copies — the direct scheme of the
 // reference (NeighbourCommunicationScheme.cpp:115-136) over the export / import entry points
+//
+// Overlap (round 4; the reference's own split: C08CellPairTraversal.h:78-192 traverseCellPairsInner / Outer driven by
+// NonBlockingMPIMultiStepHandler.cpp:30-97, which a non-MPI build of the driver never reaches): the INNER pass — bricks whose
+// cutoff shell holds owned molecules only — is queued on the engine's main stream as soon as the owned molecules are final, the
+// whole halo phase (generation or refresh, packing, the transfers on the transport's stream, import) runs while it computes, and
+// the driver's traverseCells then launches the boundary pass only, which waits on the device for the imported halo.
+// LS1HIP_OVERLAP=0 keeps one complete pass behind a blocking exchange.
 void LinkedCellsHip::exchangeAcrossRanks(DomainDecompHip& dd, Domain* domain) {
 	double glen[3];
 	for (int d = 0; d < 3; ++d) glen[d] = domain->getGlobalLength(d);
 	int rc;
+	_innerLaunched = false;
 	if (!_rebuildStep) {  // list-reuse step: current positions of the build-time halo records, nothing else travels
+		if (_overlap) {
+			deviceForces(1);  // inner bricks: owned positions only
+			_innerLaunched = true;
+		}
 		if ((rc = ls1hip_halo_refresh(_ctx))) die("ls1hip_halo_refresh", rc);
 		dd.exchange(_ctx, glen, 2);
 		return;
 	}
 	dd.exchange(_ctx, glen, 0);
-	if ((rc = ls1hip_halo(_ctx))) die("ls1hip_halo", rc);
-	dd.exchange(_ctx, glen, 1);
 	long lists = 0;
 	ls1hip_get_option(_ctx, "verlet_lists", &lists);
-	if (lists && (rc = ls1hip_verlet_build(_ctx))) die("ls1hip_verlet_build", rc);
+	if (_overlap && !lists) {  // search every step: the owned segment is sorted once the immigrants are in
+		deviceForces(1);
+		_innerLaunched = true;
+	}
+	if ((rc = ls1hip_halo(_ctx))) die("ls1hip_halo", rc);
+	dd.exchange(_ctx, glen, 1);
+	if (lists && (rc = ls1hip_verlet_build(_ctx))) die("ls1hip_verlet_build", rc);  // (a rebuild step: the build needs the halo)
 }
 
 void LinkedCellsHip::updateMoleculeCaches() {
@@ -417,7 +439,9 @@ static void require_vectorized(CellProcessor& cp) {
 
 void LinkedCellsHip::traverseCells(CellProcessor& cellProcessor) {
 	require_vectorized(cellProcessor);
-	deviceForces(0);
+	// multi-rank with overlap: the inner pass was queued inside balanceAndExchange, ahead of the halo phase
+	deviceForces(_innerLaunched ? 2 : 0);
+	_innerLaunched = false;
 }
 void LinkedCellsHip::traverseNonInnermostCells(CellProcessor& cellProcessor) {
 	require_vectorized(cellProcessor);
@@ -429,7 +453,37 @@ void LinkedCellsHip::traversePartialInnermostCells(CellProcessor& cellProcessor,
 	if (stage == 0) deviceForces(1);  // the whole inner pass is one launch: it runs entirely at stage 0
 }
 
+// Plugins whose per-step hooks run INSIDE the windows in which the host mirror is empty (beforeEventNewTimestep, beforeForces,
+// siteWiseForces, afterForces: Simulation.cpp:1001-1082) would silently find no molecule on the device path.  Known ones stop the
+// run with an explanation instead; plugins that act at endStep / finish (writers, samplers) get the refilled mirror.
+// LS1HIP_ALLOW_PLUGINS=1 lets a user take responsibility for a plugin whose overrides are empty.
+static void check_plugins_once() {
+	static const std::set<std::string> in_window = {
+		"CavityWriter", "CommunicationPartnerWriter", "FlopRateWriter", "HaloParticleWriter", "ODF", "RDF", "COMaligner", "DirectedPM",
+		"Dropaccelerator", "Dropaligner", "ExamplePlugin", "FixRegion", "InMemoryCheckpointing", "MaxCheck", "Mirror", "MirrorSystem",
+		"TestPlugin", "WallPotential", "DistControl", "DriftCtrl", "ExtractPhase", "MettDeamon", "MettDeamonFeedrateDirector", "PosNegComp",
+		"RegionSampling"};
+	if (getenv("LS1HIP_ALLOW_PLUGINS") && atoi(getenv("LS1HIP_ALLOW_PLUGINS")) != 0) return;
+	std::list<PluginBase*>* plugins = global_simulation->getPluginList();
+	if (!plugins) return;
+	for (PluginBase* p : *plugins) {
+		if (!p) continue;
+		const std::string name = p->getPluginName();
+		if (in_window.count(name)) {
+			global_log->error() << "LinkedCellsHip: plugin '" << name << "' acts on the molecules between eventNewTimestep and the thermostat "
+								   "(beforeForces / siteWiseForces / afterForces ...): on the device container those hooks see an empty host "
+								   "mirror and would silently do nothing.  Run it with the host container, or set LS1HIP_ALLOW_PLUGINS=1 if its "
+								   "hooks are known to be empty." << std::endl;
+			Simulation::exit(698);
+		}
+	}
+}
+
 void LinkedCellsHip::deviceAdvanced() {
+	if (!_pluginsChecked) {
+		_pluginsChecked = true;
+		check_plugins_once();
+	}
 	++_stepIndex;
 	_stepOpen = true;
 	_quietArmed = false;
@@ -468,25 +522,45 @@ void LinkedCellsHip::syncMirrorFromDevice(bool applyPendingBeta) {
 	mirror().clear();
 	std::vector<Molecule> mols;
 	mols.reserve(n);
-	if (_multiRank && _skin > 0.) {
-		// multi-rank list mode: a molecule awaiting migration lies outside this rank's box — the mirror would drop it
-		size_t stray = 0;
-		for (size_t i = 0; i < n; ++i)
-			for (int d = 0; d < 3; ++d)
-				if (r[3 * i + d] < _mirror.getBoundingBoxMin(d) || r[3 * i + d] >= _mirror.getBoundingBoxMax(d)) {
-					++stray;
-					break;
-				}
-		if (stray) {
-			global_log->error() << "LinkedCellsHip: " << stray << " owned molecule(s) lie outside this rank's box (multi-rank list mode: they "
-									"migrate at the next list rebuild) and a reader asked for the host mirror at step "
-								<< global_simulation->getSimulationStep()
-								<< ".  Set LS1HIP_MIRROR_SYNC_INTERVAL to the reader's period (those steps rebuild) or run without "
-									"LS1HIP_MULTIRANK_LISTS." << std::endl;
-			Simulation::exit(696);
+	// Multi-rank list mode: a molecule that awaits its migration (up to skin / 2 outside this rank's box until the next list rebuild)
+	// is handed, FOR THIS SNAPSHOT ONLY, to the rank whose box holds its periodically wrapped position — the union of the ranks'
+	// mirrors is every molecule exactly once, each inside its holder's box, whatever step a reader asks at.  Collective: every rank
+	// reaches this point together (the driver is SPMD; the mirror's readers run on all ranks).
+	struct Stray {
+		uint64_t id;
+		int64_t cid;
+		double r[3], v[3], q[4], D[3], F[3], M[3];
+	};
+	std::vector<Stray> strays;
+	std::vector<char> mine_is_stray(n, 0);
+	const bool migrate = _multiRank && _skin > 0.;
+	if (migrate) {
+		Domain* domain = global_simulation->getDomain();
+		for (size_t i = 0; i < n; ++i) {
+			bool out = false;
+			for (int d = 0; d < 3; ++d) out = out || r[3 * i + d] < _mirror.getBoundingBoxMin(d) || r[3 * i + d] >= _mirror.getBoundingBoxMax(d);
+			if (!out) continue;
+			mine_is_stray[i] = 1;
+			Stray s;
+			s.id = id[i];
+			s.cid = cid[i];
+			for (int d = 0; d < 3; ++d) {
+				const double L = domain->getGlobalLength(d);
+				double x = r[3 * i + d];
+				x -= L * std::floor(x / L);
+				if (x >= L) x = std::nextafter(L, 0.);
+				s.r[d] = x;
+				s.v[d] = betaT[cid[i]] * v[3 * i + d];
+				s.D[d] = betaR[cid[i]] * D[3 * i + d];
+				s.F[d] = haveF ? F[3 * i + d] : 0.;
+				s.M[d] = haveF ? M[3 * i + d] : 0.;
+			}
+			for (int d = 0; d < 4; ++d) s.q[d] = q[4 * i + d];
+			strays.push_back(s);
 		}
 	}
 	for (size_t i = 0; i < n; ++i) {
+		if (mine_is_stray[i]) continue;
 		const double betaTrans = betaT[cid[i]], betaRot = betaR[cid[i]];
 		Molecule m(id[i], &comps[cid[i]], r[3 * i], r[3 * i + 1], r[3 * i + 2], betaTrans * v[3 * i], betaTrans * v[3 * i + 1],
 				   betaTrans * v[3 * i + 2], q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3], betaRot * D[3 * i],
@@ -496,6 +570,45 @@ void LinkedCellsHip::syncMirrorFromDevice(bool applyPendingBeta) {
 			m.setM(&M[3 * i]);
 		}
 		mols.push_back(m);
+	}
+	if (migrate) {
+		DomainDecompHip* dd = dynamic_cast<DomainDecompHip*>(&global_simulation->domainDecomposition());
+		std::vector<char> all;
+		std::vector<size_t> counts;
+		dd->gatherRecords(strays.data(), strays.size(), sizeof(Stray), all, counts);
+		const size_t total = all.size() / sizeof(Stray);
+		size_t taken = 0;
+		for (size_t k = 0; k < total; ++k) {
+			Stray s;
+			std::memcpy(&s, all.data() + k * sizeof(Stray), sizeof(Stray));
+			bool in = true;
+			for (int d = 0; d < 3; ++d) in = in && s.r[d] >= _mirror.getBoundingBoxMin(d) && s.r[d] < _mirror.getBoundingBoxMax(d);
+			if (!in) continue;
+			Molecule m(s.id, &comps[(size_t)s.cid], s.r[0], s.r[1], s.r[2], s.v[0], s.v[1], s.v[2], s.q[0], s.q[1], s.q[2], s.q[3], s.D[0], s.D[1], s.D[2]);
+			if (haveF) {
+				m.setF(s.F);
+				m.setM(s.M);
+			}
+			mols.push_back(m);
+			++taken;
+		}
+		if (getenv("LS1HIP_LOG_SNAPSHOTS")) {
+			double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+			for (size_t i = 0; i < n; ++i)
+				for (int d = 0; d < 3; ++d) {
+					lo[d] = std::min(lo[d], r[3 * i + d]);
+					hi[d] = std::max(hi[d], r[3 * i + d]);
+				}
+			long nb = 0, ns = 0;
+			ls1hip_get_option(_ctx, "verlet_builds", &nb);
+			ls1hip_get_option(_ctx, "verlet_steps", &ns);
+			global_log->info() << "LinkedCellsHip: snapshot extent x [" << lo[0] << ", " << hi[0] << "] y [" << lo[1] << ", " << hi[1] << "] z [" << lo[2]
+							   << ", " << hi[2] << "] box x [" << _mirror.getBoundingBoxMin(0) << ", " << _mirror.getBoundingBoxMax(0) << ") builds " << nb
+							   << " list steps " << ns << std::endl;
+		}
+		if (!strays.empty() || taken || getenv("LS1HIP_LOG_SNAPSHOTS"))
+			global_log->info() << "LinkedCellsHip: snapshot at step " << global_simulation->getSimulationStep() << ": " << strays.size()
+							   << " molecule(s) awaiting migration handed over, " << taken << " taken into this rank's box" << std::endl;
 	}
 	mirror().addParticles(mols);
 	mirror().updateMoleculeCaches();

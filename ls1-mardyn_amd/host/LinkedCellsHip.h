@@ -23,7 +23,10 @@
 // Domain::calculateGlobalValues computed).  OUTSIDE those per-step windows (eventNewTimestep .. advanceSimulationTime) a reader
 // of the stale mirror — end-of-step plugins such as CheckpointWriter, the timed / final checkpoint, finishing plugins — makes
 // the container refill it from the device first (lazily synced ON DEMAND, read-only snapshot): such a reader never sees an
-// empty container.
+// empty container.  INSIDE the windows every caller of iterator() / regionIterator() finds nothing — the driver's own loops by
+// design, but also plugin hooks that run there (beforeForces, siteWiseForces, afterForces) and TemperatureControl's loops: plugins
+// known to use those hooks stop the run with an explanation (LinkedCellsHip.cpp: check_plugins_once) rather than silently doing
+// nothing; the XML thermostat type TemperatureControl is not served by the device path (use VelocityScaling).
 #pragma once
 #include <array>
 #include <future>
@@ -95,6 +98,7 @@ public:
 	// scaling of the finished step applied, which the device folds into its next kick + drift pass
 	void syncMirrorFromDevice(bool applyPendingBeta = false);
 	bool mirrorFresh() const { return _mirrorFresh; }
+	void snapshotForReaders() { ensureMirror(); }  // collective entry (DomainDecompHip::assertDisjunctivity): refill a stale mirror now
 	void stepClosed();                // eventForcesCalculated is through: only the thermostat's host loop follows in this step
 	void exchangeAcrossRanks(DomainDecompHip& dd, Domain* domain);  // multi-rank: leaving molecules + halo copies through dd's transport
 	void armPostForceKick(double dt_half) { _armedKick = dt_half; }  // the next complete traversal queues the kick behind itself
@@ -129,7 +133,10 @@ private:
 	unsigned long _stepIndex = 0;  // steps the integrator has started (eventNewTimestep)
 	bool _rebuildStep = true;   // multi-rank list mode: this step re-bins, migrates and rebuilds the lists (decided by all ranks)
 	bool _hostDirty = true;     // molecules were added / removed through the host interface since the last upload
-	bool _multiRank = false;    // more than one rank: update() only classifies, DomainDecompHip exchanges
+	bool _multiRank = false;    // more than one rank (or the loopback rehearsal): update() only classifies, DomainDecompHip exchanges
+	bool _overlap = true;       // multi-rank: the inner pass is queued ahead of the halo phase (LS1HIP_OVERLAP=0: one pass behind the exchange)
+	bool _innerLaunched = false;  // ... and it has been, for the traversal about to come
+	bool _pluginsChecked = false;
 	bool _inExchange = false;   // between update() and updateMoleculeCaches(): the driver's exchangeMolecules window
 	bool _stepOpen = false;     // between eventNewTimestep and eventForcesCalculated
 	bool _quietArmed = false;   // after eventForcesCalculated until the driver advances the simulation time (thermostat loop)

@@ -101,8 +101,7 @@ int main(int argc, char** argv) {
 		}
 		chk(ctx, ls1hip_upload(ctx, mid.size(), mid.data(), mcid.data(), mr.data(), mv.data(), mq.data(), mD.data()), "ls1hip_upload");
 
-		const char* idf = getenv("LS1HIP_RCCL_ID_FILE");
-		ls1hip::RcclTransport tr(world, rank, local, idf ? idf : "/tmp/ls1hip_rccl_id");
+		ls1hip::RcclTransport tr(world, rank, local, world > 1 ? ls1hip::rccl_id_source_from_env() : std::string());
 		ls1hip::DecomposedLoop loop(dc, ctx, tr);
 		const ls1hip::GlobalValues g0 = loop.initial_forces();
 		ls1hip::GlobalValues g = g0;

@@ -60,6 +60,7 @@
 #define LS1_HOOK_STORE(ptr, val) (*(ptr) = (val))
 #define LS1_HOOK_RECORD_OF(did) (did)
 #define LS1_HOOK_OWN_FROM_LDS true
+#define LS1_HOOK_DMA_STAGING true
 #endif
 
 namespace ls1 {
@@ -643,6 +644,61 @@ __device__ __forceinline__ void stage_positions(const ForceParams& P, const Bric
 	}
 }
 
+// LDS-DMA form of the staging for REGULAR bricks (gfx950 global_load_lds_dword: per-lane global source, wave-uniform LDS base +
+// lane * 4, no VGPR destination, no ds_write): the region image in LDS is, row by row, exactly the global layout — a region row
+// of six x-neighbour cells is one contiguous run of molecules in the cell-sorted arrays (several runs where halo cells, which live
+// in their own segment, interrupt it) — so every run is copied dword-wise by one wave: three rows per wave, descriptors through
+// scalar loads of the build's record.  8-byte alignment of both sides is enough for the dword form (the 16-byte form would need
+// runs padded to even molecule counts on both sides, i.e. another list-entry encoding).  tools/probes/glds_probe.hip checks the
+// semantics the copy relies on (EXEC-masked lanes write nothing, unaligned-to-16 runs land bit-exactly).
+typedef __attribute__((address_space(3))) void* ls1_lds_ptr;
+typedef const __attribute__((address_space(1))) void* ls1_glb_ptr;
+__device__ __forceinline__ void stage_positions_dma(const ForceParams& P, const uint32_t* __restrict__ rec, double* sx, double* sy, double* sz,
+													uint32_t total) {
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+	auto copy_run = [&](uint32_t s0, uint32_t g0, uint32_t n) {  // n molecules from global index g0 to LDS slot s0 (all wave-uniform)
+		const uint32_t nd = 2u * n;
+		const uint32_t* const gx = reinterpret_cast<const uint32_t*>(P.x + g0);
+		const uint32_t* const gy = reinterpret_cast<const uint32_t*>(P.y + g0);
+		const uint32_t* const gz = reinterpret_cast<const uint32_t*>(P.z + g0);
+		uint32_t* const lx = reinterpret_cast<uint32_t*>(sx + VPS * s0);
+		uint32_t* const ly = reinterpret_cast<uint32_t*>(sy + VPS * s0);
+		uint32_t* const lz = reinterpret_cast<uint32_t*>(sz + VPS * s0);
+		for (uint32_t k0 = 0; k0 < nd; k0 += 64u) {
+			const uint32_t d = k0 + (uint32_t)lane;
+			if (d < nd) {
+				__builtin_amdgcn_global_load_lds((ls1_glb_ptr)(gx + d), (ls1_lds_ptr)(lx + k0), 4, 0, 0);
+				__builtin_amdgcn_global_load_lds((ls1_glb_ptr)(gy + d), (ls1_lds_ptr)(ly + k0), 4, 0, 0);
+				__builtin_amdgcn_global_load_lds((ls1_glb_ptr)(gz + d), (ls1_lds_ptr)(lz + k0), 4, 0, 0);
+			}
+		}
+	};
+	static_assert(VPS == 1, "the DMA staging copies the separate x / y / z arrays");
+	for (int r = wv; r < VRY * VRZ; r += VNW) {
+		const uint32_t* const cs = rec + r * VRX;
+		const uint32_t* const gb = rec + VREC_GBEG + r * VRX;
+		uint32_t run_s = cs[0], run_g = gb[0], run_n = 0;
+#pragma unroll
+		for (int c = 0; c < VRX; ++c) {
+			const uint32_t n = cs[c + 1] - cs[c], g = gb[c];
+			if (g != run_g + run_n) {  // the cell does not follow its predecessor in memory (halo segment / domain face)
+				if (run_n) copy_run(run_s, run_g, run_n);
+				run_s = cs[c];
+				run_g = g;
+				run_n = 0;
+			}
+			run_n += n;
+		}
+		if (run_n) copy_run(run_s, run_g, run_n);
+	}
+	if (tid < 8) {
+		sx[VPS * (total + tid)] = VFAR;
+		sy[VPS * (total + tid)] = VFAR;
+		sz[VPS * (total + tid)] = VFAR;
+	}
+}
+
 // ---- BUILD ------------------------------------------------------------------------------------------------------------
 // The list only has to be a SUPERSET of the pairs within rc + skin (the force pass re-tests every entry exactly in FP64),
 // so the search runs in FP32 on brick-relative coordinates with a conservative threshold: packed FP32 arithmetic handles
@@ -938,8 +994,10 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet(ForceParams P, int n
 		head = load_list_head(P, did, wv, lane);  // list head and own indices: independent of everything staged below
 		ii0 = f_ii[tid];
 		gi0 = f_gi[tid];
-		if (LS1_HOOK_STAGING(P))  // (true)
-			stage_positions(P, R, sx, sy, sz, TotalOf{rec_total});
+		if (LS1_HOOK_STAGING(P)) {  // (true)
+			if (LS1_HOOK_DMA_STAGING) stage_positions_dma(P, srec, sx, sy, sz, rec_total);
+			else stage_positions(P, R, sx, sy, sz, TotalOf{rec_total});
+		}
 	}
 	__syncthreads();
 	if (rec_flags & 1u) {  // uniform per workgroup

@@ -62,3 +62,11 @@
 #define LS1_HOOK_RECORD_OF(did) (did)
 #define LS1_HOOK_OWN_FROM_LDS true
 #endif
+
+//   -DLS1_X_REGSTAGE     the region of a regular brick is staged through registers (global_load + ds_write, the round-3 form) instead
+//                        of by LDS-DMA (correct results; profiles/r4_ab_lds_dma_staging.txt)
+#if defined(LS1_X_REGSTAGE)
+#define LS1_HOOK_DMA_STAGING false
+#else
+#define LS1_HOOK_DMA_STAGING true
+#endif

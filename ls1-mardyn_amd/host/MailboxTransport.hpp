@@ -13,8 +13,10 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cctype>
 #include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -30,6 +32,15 @@ public:
 	MailboxTransport(int world, int rank, const std::string& dir, double timeout_s = 300.) : _world(world), _rank(rank), _dir(dir), _timeout(timeout_s) {
 		if (_dir.empty()) throw std::runtime_error("MailboxTransport: no directory (LS1HIP_COMM_DIR)");
 		mkdir(_dir.c_str(), 0700);  // (exists already for all ranks but the first)
+		// Messages are keyed by (job key, tag, src, dst, seq) with seq starting at 0 in every process: files a crashed or killed
+		// earlier run left in the directory must not be taken for this run's.  The job key comes from the launcher's environment,
+		// which every rank of a job shares without talking (LS1HIP_JOB_KEY, else the launcher's run id / rendezvous port); give
+		// every run a fresh directory where the launcher sets none of them (the tests do: mkdtemp).
+		for (const char* k : {"LS1HIP_JOB_KEY", "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "MASTER_PORT"})
+			if (const char* e = getenv(k)) {
+				for (const char* c = e; *c; ++c) _key += (isalnum((unsigned char)*c) ? *c : '-');
+				break;
+			}
 	}
 	int world() const { return _world; }
 	int rank() const { return _rank; }
@@ -96,13 +107,14 @@ private:
 		int peer;
 	};
 	std::string name(const char* tag, int src, int dst, uint64_t seq) const {
-		return _dir + "/" + tag + "_" + std::to_string(src) + "_" + std::to_string(dst) + "_" + std::to_string(seq);
+		return _dir + "/" + (_key.empty() ? std::string() : _key + "_") + tag + "_" + std::to_string(src) + "_" + std::to_string(dst) + "_" + std::to_string(seq);
 	}
 	void put(const char* tag, int dst, uint64_t seq, const void* data, size_t n) {
 		const std::string fin = name(tag, _rank, dst, seq), tmp = fin + ".tmp";
 		FILE* f = fopen(tmp.c_str(), "wb");
-		if (!f || (n && fwrite(data, 1, n, f) != n)) throw std::runtime_error("MailboxTransport: cannot write " + tmp);
-		fclose(f);
+		const bool ok = f && (!n || fwrite(data, 1, n, f) == n);
+		if (f && fclose(f) != 0) throw std::runtime_error("MailboxTransport: cannot write " + tmp + " (directory full?)");
+		if (!ok) throw std::runtime_error("MailboxTransport: cannot write " + tmp);
 		if (rename(tmp.c_str(), fin.c_str())) throw std::runtime_error("MailboxTransport: cannot publish " + fin);
 	}
 	void get(const char* tag, int src, uint64_t seq, void* data, size_t n) {
@@ -124,7 +136,7 @@ private:
 	}
 
 	int _world, _rank;
-	std::string _dir;
+	std::string _dir, _key;
 	double _timeout;
 	uint64_t _coll_seq = 0;
 	std::map<int, uint64_t> _send_seq, _recv_seq;

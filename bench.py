@@ -291,6 +291,53 @@ def mixed_box(inp, n):
     return ps
 
 
+def multi_gpu_self_check(comps, world, rank, local_rank, rehearse, torch, dist):
+    """First action of an N > 1 run (ADVICE r1 / VERDICT r3 #9): a small box (2 * 24^3 molecules) split over the N ranks exactly as
+    the timed box will be — every rank generates its sub-box, leaving molecules and halo copies travel through the same transport —
+    against the SAME box held whole by this rank alone: forces of the molecules this rank owns (1e-12 of max|F|; not bitwise: the
+    ranks' cell grids differ from the single domain's, so sums run in another order) and the global U_pot / virial.  A mismatch
+    stops the run before anything is timed."""
+    decomp = importlib.import_module("ls1-mardyn_amd.decomp")
+    synth = importlib.import_module("ls1-mardyn_amd.synth")
+    engine_mod = importlib.import_module("ls1-mardyn_amd.engine")
+    n = 24
+    sim = decomp.build_strong_scaling_box(comps, RC, n, world, rank, local_rank, rho=RHO, temp=TEMP, stage_through_host=rehearse)
+    macro = sim.initial_forces()
+    g = sim.reduce_globals(macro, (0.0, 0.0, 0, 0))
+    st = sim.engine.download_state()
+    F = sim.engine.download_forces()["F"]
+    sim.engine.close()
+    L, ids, r, v = synth.bcc_box(n, rho=RHO, temp=TEMP)
+    e1 = engine_mod.DeviceEngine(local_rank)
+    e1.set_components(comps, RC)
+    e1.set_domain([L, L, L])
+    e1.upload(ids, np.zeros(len(ids), np.int32), r, v)
+    e1.rebin(); e1.halo()
+    u1, w1 = e1.forces(0)
+    s1 = e1.download_state()
+    F1 = e1.download_forces()["F"]
+    e1.close()
+    o1 = np.argsort(s1["ids"], kind="stable")
+    pos = np.searchsorted(s1["ids"][o1], st["ids"])
+    Fref = F1[o1][pos]
+    ok_ids = bool(np.array_equal(s1["ids"][o1][pos], st["ids"]))
+    df = float(np.max(np.abs(F - Fref)) / np.max(np.abs(F1))) if len(F) else 0.0
+    du, dw = abs(g["upot"] - u1) / abs(u1), abs(g["virial"] - w1) / abs(w1)
+    t = torch.tensor([df, du, dw, 0.0 if ok_ids else 1.0, float(len(F))], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+    tm = t.clone()
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    ts = t.clone()
+    dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+    res = {"molecules": int(2 * n ** 3), "owned_molecules_summed_over_ranks": int(ts[4].item()), "forces_max_rel_over_ranks": float(tm[0].item()),
+           "upot_rel": float(tm[1].item()), "virial_rel": float(tm[2].item()), "ids_match": tm[3].item() == 0.0,
+           "what": "2*24^3 box split over the ranks (own sub-box generation, leaving + halo exchange through the run's transport) vs the same "
+                   "box whole on every rank alone, before anything is timed"}
+    if not (res["ids_match"] and res["owned_molecules_summed_over_ranks"] == res["molecules"] and res["forces_max_rel_over_ranks"] < 1e-11
+            and res["upot_rel"] < 1e-11 and res["virial_rel"] < 1e-10):
+        sys.exit(f"bench.py: the decomposed path disagrees with the single domain on the start-up check: {res}")
+    return res
+
+
 PMC_TRAFFIC = (("FETCH_SIZE",), ("WRITE_SIZE",))
 PMC_COMPUTE = (("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_WAVES", "GRBM_GUI_ACTIVE"),
                ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64",
@@ -471,6 +518,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         decomp = importlib.import_module("ls1-mardyn_amd.decomp")
+        self_check = multi_gpu_self_check(comps, world, rank, local_rank, rehearse, torch, dist) if world > 1 and not args.pmc_child else None
         sim = decomp.build_strong_scaling_box(comps, RC, n, world, rank, local_rank, rho=RHO, temp=TEMP,
                                               cic=args.cic or None, kernel=args.kernel, stage_through_host=rehearse,
                                               loopback=args.loopback,
@@ -791,6 +839,7 @@ def main():
             out["roofline"]["compute"] = comp
         if world > 1:
             out["rccl_world_size"] = world_seen
+            out["multi_gpu_self_check"] = self_check
             out["config"]["molecules_per_gpu_by_rank"] = per_rank
             out["config"]["transport"] = "gloo staged through the host (rehearsal)" if rehearse else "RCCL (torch.distributed nccl backend)"
         if not args.no_cpu_baseline and world == 1:

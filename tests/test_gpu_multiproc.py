@@ -83,3 +83,33 @@ def test_ranks_in_separate_processes_match_the_oracle(world, grid, mode):
     assert abs(z["virial"] - o["virial"]) < 1e-9 * abs(o["virial"])
     assert abs(z["summv2"] - o["summv2"]) < 1e-11 * o["summv2"]
     assert int(z["n"]) == len(ids)
+
+
+def test_bench_py_launched_as_the_driver_launches_it_with_two_ranks():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...`
+    — the driver's own command line for N > 1 — on the one GPU of the test box (LS1_BENCH_BACKEND=gloo: both ranks on cuda:0, messages
+    staged through the host; the rates are meaningless).  Rank 0 must print ONE JSON line with the contract's fields, the start-up
+    check of the decomposed path against the single domain, the communicator's world size and every rank's molecule
+    count, strong scaling (the ranks' molecules add up to the global box)."""
+    import json
+    n = 48  # 2 * 48^3 = 221 184 molecules split 2 x 1 x 1
+    env = dict(os.environ, LS1_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2",
+           "--n-per-dim", str(n), "--melt", "0", "--no-live-pmc", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["warmup"] == 2 and d["scaling"] == "strong" and d["unit"] == "particle-updates/s"
+    assert d["rccl_world_size"] == 2
+    per = d["config"]["molecules_per_gpu_by_rank"]
+    assert len(per) == 2 and sum(per) == 2 * n ** 3 and min(per) > 0
+    sc = d["multi_gpu_self_check"]
+    assert sc["ids_match"] and sc["owned_molecules_summed_over_ranks"] == sc["molecules"]
+    assert sc["forces_max_rel_over_ranks"] < 1e-11 and sc["upot_rel"] < 1e-11
+    assert abs(d["value"] - 2 * n ** 3 * 8 / (d["ms_per_step"] * 8e-3)) <= 1e-6 * d["value"]

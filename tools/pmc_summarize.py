@@ -84,6 +84,8 @@ if trace and fk:
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     cfgb = bench.get("config", {}).get("untimed_steps_before_the_timed_window", {})
     first = int(cfgb.get("melt", 0)) + int(cfgb.get("warmup", bench.get("warmup", 0)))
+    # (round 4: the melt phase is extended by a few steps that place the timed window in the list lifetime)
+    first += int((bench.get("config", {}).get("timed_window") or {}).get("extra_untimed_steps_for_alignment", 0))
     win = rows[first:first + int(bench["steps"])]
     if win:
         d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in win]

@@ -214,7 +214,10 @@ static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
 		if (which != 0) FAIL(c, LS1HIP_EINVAL, "multi-site neighbour lists serve complete traversals (which = 0)");
 		bool lj_only = true;
 		for (int k = 0; k < c->h_ct.ncomp; ++k) lj_only = lj_only && c->h_ct.nc[k] == 0 && c->h_ct.nd[k] == 0 && c->h_ct.nq[k] == 0;
-		done = launch_force_ms_list(P, c->h_ct.has_rot != 0, lj_only, c->h_ct.ncomp, c->d_msl_off, c->d_msl_j, c->d_msl_il, c->d_shift27, c->d_msl_pk,
+		// linear molecules (every LJ centre on the body z axis: ethane, the 2CLJ family): the axis form of the orientation
+		bool linear = lj_only;
+		for (int k = 0; k < c->h_ct.ncenters && linear; ++k) linear = c->h_ct.ljpos[k][0] == 0. && c->h_ct.ljpos[k][1] == 0.;
+		done = launch_force_ms_list(P, c->h_ct.has_rot != 0, lj_only, linear, c->h_ct.ncomp, c->d_msl_off, c->d_msl_j, c->d_msl_il, c->d_shift27, c->d_msl_pk,
 									c->stream, &nblocks, c->partials_cap);
 		if (!done) FAIL(c, LS1HIP_EINVAL, "multi-site neighbour-list force pass could not be launched");
 		family = LS1HIP_FK_NEIGHBOUR_LIST;

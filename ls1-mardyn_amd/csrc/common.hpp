@@ -381,7 +381,7 @@ void launch_msl_count(const ForceParams& p, uint32_t* grp_cnt, uint32_t* off, ui
 					  hipStream_t s);
 void launch_msl_fill(const ForceParams& p, const uint32_t* off, const uint32_t* hsrc, const uint8_t* hdir, uint32_t* out_j,
 					 uint8_t* out_il, int ncomp, const uint32_t* scratch, const uint16_t* mcnt, uint32_t stride, hipStream_t s);
-bool launch_force_ms_list(const ForceParams& p, bool has_rot, bool lj_only, int ncomp, const uint32_t* off, const uint32_t* pj, const uint8_t* pil,
+bool launch_force_ms_list(const ForceParams& p, bool has_rot, bool lj_only, bool linear, int ncomp, const uint32_t* off, const uint32_t* pj, const uint8_t* pil,
 						  const double* shift27, double* pk, hipStream_t s, uint32_t* nblocks, size_t partials_cap);
 // kin_in_slot1: the partials' slot 1 carries sum m v^2 of a fused force + integration pass (goes to cnt->kin[0], not to
 // the macroscopic sums); log (may be null): the step-log row {U_pot, virial, sum m v^2, sum I w^2, N, rotDOF} to refresh

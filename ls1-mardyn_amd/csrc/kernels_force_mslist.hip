@@ -48,6 +48,8 @@ __device__ __forceinline__ double msl_rsq(double d) {
 }  // namespace ls1
 #define LS1_PAIR_RCP(x) ::ls1::msl_rcp(x)
 #define LS1_PAIR_SQRT(x) ((x) * ::ls1::msl_rsq(x))
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace ls1 {
@@ -261,7 +263,11 @@ __global__ void __launch_bounds__(256) k_msl_pack(ForceParams P, double* __restr
 // ---- REUSE: forces from the pair stream, one wave per group ----------------------------------------------------------------------
 // LJ_ONLY: no electrostatic sites in the component set — the multipole bodies are compiled out, the kernel needs half the
 // registers (four waves per SIMD instead of two: the gathers of a latency-bound pair stream want the occupancy)
-template <bool WITH_ROT, bool LJ_ONLY>
+// LINEAR (with LJ_ONLY): every site of the set lies on the body z axis (ethane, the 2CLJ family): orientations are carried as the
+// rotated z axis (RotAxis, pairphys.hpp) — 24 VGPRs fewer than two rotation matrices (112 instead of 136), a third of the rotation
+// arithmetic.  (The occupancy stays at three waves per SIMD: 14 KB of LDS per wave; groups of 64 molecules would lift it to four
+// but were not built — MSG is baked into the list format.)
+template <bool WITH_ROT, bool LJ_ONLY, bool LINEAR = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_force_ms_list(ForceParams P, const uint32_t* __restrict__ off, const uint32_t* __restrict__ pj,
 													  const uint8_t* __restrict__ pil, const double* __restrict__ shift27,
 													  const double* __restrict__ pk, const CompTable* __restrict__ ctab) {
@@ -362,12 +368,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
 		const double dd = dot(drm, drm);
 		const bool in = valid && dd < rc2 && dd != 0.;
 		int tkey = 0;
-		Rot Ri = rot_of(1., 0., 0., 0.), Rj = Ri;
+		using RotT = typename std::conditional<LINEAR, RotAxis, Rot>::type;
+		RotT Ri, Rj;
+		if constexpr (LINEAR) Ri = Rj = rot_axis_of(1., 0., 0., 0.);
+		else Ri = Rj = rot_of(1., 0., 0., 0.);
 		if (in) {
 			if (ncomp > 1) tkey = sci[k] * MAXC + cur.cj;
 			if (WITH_ROT) {
-				Ri = rot_of(sq[0][k], sq[1][k], sq[2][k], sq[3][k]);
-				Rj = rot_of(cur.q0, cur.q1, cur.q2, cur.q3);  // (normalised by k_msl_pack)
+				if constexpr (LINEAR) {
+					Ri = rot_axis_of(sq[0][k], sq[1][k], sq[2][k], sq[3][k]);
+					Rj = rot_axis_of(cur.q0, cur.q1, cur.q2, cur.q3);  // (normalised by k_msl_pack)
+				} else {
+					Ri = rot_of(sq[0][k], sq[1][k], sq[2][k], sq[3][k]);
+					Rj = rot_of(cur.q0, cur.q1, cur.q2, cur.q3);  // (normalised by k_msl_pack)
+				}
 			}
 		}
 		a.F = {0., 0., 0.};
@@ -384,7 +398,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
 				// the compiler substitutes the lane's own key — it knows tkey == t here — and every table load behind it becomes a
 				// per-lane vector load with its own latency chain)
 				const int ci_u = __builtin_amdgcn_readfirstlane(tkey) / MAXC, cj_u = __builtin_amdgcn_readfirstlane(tkey) % MAXC;
-				mol_pair<false, ConstCompTable, LJ_ONLY>(ct, ci_u, ri, Ri, cj_u, rj, Rj, drm, dd < rclj2, 0.5, a);
+				mol_pair<false, ConstCompTable, LJ_ONLY, RotT>(ct, ci_u, ri, Ri, cj_u, rj, Rj, drm, dd < rclj2, 0.5, a);
 			}
 			todo &= ~__ballot(mine);
 		}
@@ -443,14 +457,15 @@ void launch_msl_fill(const ForceParams& p, const uint32_t* off, const uint32_t* 
 	hipLaunchKernelGGL(k_msl_fill, dim3(ng), dim3(MSG), 0, s, p, off, hsrc, hdir, out_j, out_il, ncomp, scratch, mcnt, stride);
 }
 
-bool launch_force_ms_list(const ForceParams& p, bool has_rot, bool lj_only, int ncomp, const uint32_t* off, const uint32_t* pj, const uint8_t* pil,
+bool launch_force_ms_list(const ForceParams& p, bool has_rot, bool lj_only, bool linear, int ncomp, const uint32_t* off, const uint32_t* pj, const uint8_t* pil,
 						  const double* shift27, double* pk, hipStream_t s, uint32_t* nblocks, size_t partials_cap) {
 	const uint32_t ng = msl_groups(p.n_real_cap);
 	if ((size_t)ng > partials_cap || p.which != 0) return false;
 	*nblocks = ng;
 	if (ng == 0) return true;
 	hipLaunchKernelGGL(k_msl_pack, dim3((p.n_real_cap + 255u) / 256u), dim3(256), 0, s, p, pk, has_rot ? 1 : 0, ncomp);
-	if (has_rot && lj_only) hipLaunchKernelGGL((k_force_ms_list<true, true>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);
+	if (has_rot && lj_only && linear) hipLaunchKernelGGL((k_force_ms_list<true, true, true>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);
+	else if (has_rot && lj_only) hipLaunchKernelGGL((k_force_ms_list<true, true>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);
 	else if (has_rot) hipLaunchKernelGGL((k_force_ms_list<true, false>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);
 	else if (lj_only) hipLaunchKernelGGL((k_force_ms_list<false, true>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);
 	else hipLaunchKernelGGL((k_force_ms_list<false, false>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);

@@ -42,9 +42,11 @@ LS1_HD V3 ld3(const T3& t, int k) {  // t: double [n][3] in any address space
 // CT: CompTable in any address space (kernels_force_mslist.hip reads it through the constant address space, so that the
 // table loads behind its wave-uniform component indices become scalar loads)
 // LJ_ONLY: the component set has no charges, dipoles or quadrupoles (their loops — and their registers — are compiled out)
-template <bool WITH_VI, class CT = CompTable, bool LJ_ONLY = false>
-LS1_HD void mol_pair(const CT& ct, int ci, V3 ri, const Rot& Ri, int cj, V3 rj, const Rot& Rj, V3 drm,
+// ROT: Rot (general) or RotAxis (every site of the component set on the body z axis; LJ_ONLY sets only)
+template <bool WITH_VI, class CT = CompTable, bool LJ_ONLY = false, class ROT = Rot>
+LS1_HD void mol_pair(const CT& ct, int ci, V3 ri, const ROT& Ri, int cj, V3 rj, const ROT& Rj, V3 drm,
 					 bool calcLJ, double w, MolAcc& a) {
+	static_assert(LJ_ONLY || sizeof(ROT) == sizeof(Rot), "the axis form serves LJ-only component sets");
 	V3 Fp = {0., 0., 0.};  // force on i from this pair (for the virial)
 	double u6 = 0., uX = 0., rf = 0.;
 	V3 f, m1, m2;

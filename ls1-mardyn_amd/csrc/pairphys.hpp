@@ -69,6 +69,17 @@ LS1_HD V3 rotate(const Rot& R, V3 d) {
 	return {R.m[0] * d.x + R.m[1] * d.y + R.m[2] * d.z, R.m[3] * d.x + R.m[4] * d.y + R.m[5] * d.z,
 			R.m[6] * d.x + R.m[7] * d.y + R.m[8] * d.z};
 }
+// LINEAR molecules (every site on the body z axis: the 2CLJ / 2CLJQ / 2CLJD family, ethane): a site offset (0, 0, d) turns into
+// d times the third COLUMN of the rotation matrix — three doubles per molecule instead of nine, one multiplication per component
+// instead of three (the products with the zero components vanish exactly, so the result is the full matrix's to the last bit
+// except for the sign of zeros).  Used by the LJ-only pair-stream kernel (kernels_force_mslist.hip).
+struct RotAxis {
+	V3 ez;
+};
+LS1_HD RotAxis rot_axis_of(double w, double x, double y, double z) {
+	return {{2. * (w * y + x * z), 2. * (y * z - w * x), w * w - x * x - y * y + z * z}};
+}
+LS1_HD V3 rotate(const RotAxis& R, V3 d) { return {R.ez.x * d.z, R.ez.y * d.z, R.ez.z * d.z}; }
 // Quaternion::rotateinv (Quaternion.cpp:63-81) = transpose.
 LS1_HD V3 rotate_inv(const Rot& R, V3 d) {
 	return {R.m[0] * d.x + R.m[3] * d.y + R.m[6] * d.z, R.m[1] * d.x + R.m[4] * d.y + R.m[7] * d.z,

@@ -64,6 +64,42 @@ __device__ __forceinline__ uint32_t msl_wave_sum(uint32_t v) {
 	for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
 	return v;
 }
+// ---- run accumulation (LJ-only sets) ---------------------------------------------------------------------------------------
+// The pairs of a block are sorted by (component pair, local molecule): the lanes of a trip that feed the SAME accumulator are
+// neighbours.  Their contributions are summed across lanes first — a segmented inclusive scan inside every row of 16 lanes with DPP
+// row shifts (VALU only: no LDS, no cross-row traffic) — and only the LAST lane of a run (inside its row) adds to the LDS
+// accumulator: one ds_add_f64 per run and row instead of one per pair, and what is left hardly ever meets another lane on the same
+// address (ethane: runs of ~10 pairs; the same-address adds were 38 % of the kernel's LDS cycles).  Deterministic:
+// the association of the sums is fixed by the lane positions.
+template <int CTRL>
+__device__ __forceinline__ int msl_dpp_i(int old, int v) {
+	return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false);  // lanes without a source keep `old`
+}
+template <int CTRL>
+__device__ __forceinline__ double msl_dpp_d(double v) {
+	const int lo = msl_dpp_i<CTRL>(0, __double2loint(v)), hi = msl_dpp_i<CTRL>(0, __double2hiint(v));
+	return __hiloint2double(hi, lo);
+}
+template <int CTRL, int N>
+__device__ __forceinline__ void msl_seg_step(int key, double (&val)[N]) {
+	const bool same = msl_dpp_i<CTRL>(-1, key) == key;  // the lane CTRL's shift away (same row) feeds the same accumulator
+#pragma unroll
+	for (int c = 0; c < N; ++c) {
+		const double t = msl_dpp_d<CTRL>(val[c]);
+		val[c] += same ? t : 0.;
+	}
+}
+// after the call: val = sum over the lane's run up to and including the lane (inside its row of 16); returns whether the lane is
+// the last of its run inside the row (the one that stores)
+template <int N>
+__device__ __forceinline__ bool msl_run_sums(int key, double (&val)[N]) {
+	msl_seg_step<0x111>(key, val);  // row_shr:1
+	msl_seg_step<0x112>(key, val);  // row_shr:2
+	msl_seg_step<0x114>(key, val);  // row_shr:4
+	msl_seg_step<0x118>(key, val);  // row_shr:8
+	return msl_dpp_i<0x101>(-2, key) != key;  // row_shl:1: the next lane of the row (none: the lane ends its row)
+}
+
 __device__ __forceinline__ double msl_wave_sum_d(double v) {
 	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
 	return v;
@@ -402,7 +438,30 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
 			}
 			todo &= ~__ballot(mine);
 		}
-		if (in) {
+#if defined(LS1_BUILD_VARIANT) && defined(LS1_X_NO_RUNSUM)
+		constexpr bool RUNSUM = false;  // (A/B: one ds_add_f64 per pair, the round-3 form)
+#else
+		constexpr bool RUNSUM = LJ_ONLY;
+#endif
+		if constexpr (RUNSUM) {
+			// run accumulation (see msl_run_sums): every lane takes part in the row shifts; out-of-range and padding lanes carry
+			// zeros, padding lanes (il = 0xff) share the key -1 and never store
+			double val[WITH_ROT ? 6 : 3];
+			val[0] = in ? a.F.x : 0.;
+			val[1] = in ? a.F.y : 0.;
+			val[2] = in ? a.F.z : 0.;
+			if constexpr (WITH_ROT) {
+				val[3] = in ? a.M.x : 0.;
+				val[4] = in ? a.M.y : 0.;
+				val[5] = in ? a.M.z : 0.;
+			}
+			const int key = valid ? (int)k : -1;
+			const bool tail = msl_run_sums(key, val);
+			if (tail && valid) {
+#pragma unroll
+				for (int c = 0; c < (WITH_ROT ? 6 : 3); ++c) unsafeAtomicAdd(&acc[c][k], val[c]);
+			}
+		} else if (in) {
 			unsafeAtomicAdd(&acc[0][k], a.F.x);
 			unsafeAtomicAdd(&acc[1][k], a.F.y);
 			unsafeAtomicAdd(&acc[2][k], a.F.z);

@@ -397,6 +397,7 @@ extern "C" int ls1hip_set_domain(ls1hip_ctx* c, const double global_len[3], cons
 	c->binned = false;
 	c->halo_valid = false;
 	c->forces_valid = false;
+	c->msl_pk_fresh = false;
 	return LS1HIP_OK;
 }
 
@@ -537,6 +538,7 @@ extern "C" int ls1hip_upload_begin(ls1hip_ctx* c, size_t n) {
 	c->n_real = 0;
 	c->n_halo = 0;
 	c->binned = c->halo_valid = c->forces_valid = false;
+	c->msl_pk_fresh = false;
 	c->pos_x = c->pos_y = c->pos_z = nullptr;
 	c->vl_ready = false;
 	c->vl_bound_pending = false;

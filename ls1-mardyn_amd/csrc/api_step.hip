@@ -69,6 +69,7 @@ int do_rebin_finish(ls1hip_ctx* c, uint32_t n_in) {
 	c->binned = true;
 	c->halo_valid = false;
 	c->forces_valid = false;
+	c->msl_pk_fresh = false;
 	return LS1HIP_OK;
 }
 
@@ -110,6 +111,7 @@ extern "C" int ls1hip_halo(ls1hip_ctx* c) {
 	}
 	HIPCHK(c, hipGetLastError());
 	c->forces_valid = false;
+	c->msl_pk_fresh = false;
 	return LS1HIP_OK;
 }
 
@@ -218,7 +220,7 @@ static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
 		bool linear = lj_only;
 		for (int k = 0; k < c->h_ct.ncenters && linear; ++k) linear = c->h_ct.ljpos[k][0] == 0. && c->h_ct.ljpos[k][1] == 0.;
 		done = launch_force_ms_list(P, c->h_ct.has_rot != 0, lj_only, linear, c->h_ct.ncomp, c->d_msl_off, c->d_msl_j, c->d_msl_il, c->d_shift27, c->d_msl_pk,
-									c->stream, &nblocks, c->partials_cap);
+									c->stream, &nblocks, c->partials_cap, c->msl_pk_fresh);
 		if (!done) FAIL(c, LS1HIP_EINVAL, "multi-site neighbour-list force pass could not be launched");
 		family = LS1HIP_FK_NEIGHBOUR_LIST;
 	} else if (fp.vl) {
@@ -336,6 +338,7 @@ extern "C" int ls1hip_forces_kick_drift(ls1hip_ctx* c, int which, double dt, dou
 		c->binned = false;
 		c->halo_valid = false;
 		c->forces_valid = false;
+		c->msl_pk_fresh = false;
 	}
 	if (upot || virial) {
 		int rc = sync_counters(c);
@@ -382,6 +385,11 @@ static IntegArgs integ_args_lists(ls1hip_ctx* c, double dt) {
 		a.mol.z = c->pos_z;
 	}
 	a.vmax_part = c->d_partials;
+	// rigid bodies under pair-stream lists: the pass also writes the records the next force pass reads (instead of k_msl_pack)
+	if (!c->one_clj && c->h_ct.has_rot && c->vl_ready && c->d_msl_pk && (size_t)c->n_real <= c->msl_stride) {
+		a.pk = c->d_msl_pk;
+		a.pk_ncomp = c->h_ct.ncomp;
+	}
 	return a;
 }
 // beta: the thermostat factor the drift pass applied to the velocities (host value), or < 0: it took cnt->beta[0] on the device
@@ -415,10 +423,12 @@ static int kick_drift_impl(ls1hip_ctx* c, double dt, int pre_scale, double bt, d
 		if (rcm) return rcm;
 	}
 	TimedScope ts(c, c->t_integrate);
+	bool wrote_pk = false;
 	if (c->vl_ready) {
 		IntegArgs a = integ_args_lists(c, dt);
 		a.pre_scale = pre_scale; a.pre_bt = bt; a.pre_br = br;
 		launch_kick_drift(a, c->stream);
+		wrote_pk = a.pk != nullptr;
 		int rcb = track_unfused_drift(c, dt, pre_scale == 0 ? 1. : pre_scale == 2 ? -1. : bt);
 		if (rcb) return rcb;
 	} else {
@@ -430,6 +440,7 @@ static int kick_drift_impl(ls1hip_ctx* c, double dt, int pre_scale, double bt, d
 	c->binned = false;
 	c->halo_valid = false;
 	c->forces_valid = false;
+	c->msl_pk_fresh = wrote_pk;
 	return LS1HIP_OK;
 }
 
@@ -443,8 +454,11 @@ extern "C" int ls1hip_kick_then_kick_drift(ls1hip_ctx* c, double dt) {
 		if (rcm) return rcm;
 	}
 	TimedScope ts(c, c->t_integrate);
+	bool wrote_pk = false;
 	if (c->vl_ready) {
-		launch_kick_then_kick_drift(integ_args_lists(c, dt), c->stream);
+		const IntegArgs a = integ_args_lists(c, dt);
+		launch_kick_then_kick_drift(a, c->stream);
+		wrote_pk = a.pk != nullptr;
 		int rcb = track_unfused_drift(c, dt);
 		if (rcb) return rcb;
 	} else {
@@ -454,6 +468,7 @@ extern "C" int ls1hip_kick_then_kick_drift(ls1hip_ctx* c, double dt) {
 	c->binned = false;
 	c->halo_valid = false;
 	c->forces_valid = false;
+	c->msl_pk_fresh = wrote_pk;
 	return LS1HIP_OK;
 }
 
@@ -536,6 +551,7 @@ extern "C" int ls1hip_scale_kick_drift_components(ls1hip_ctx* c, int ncomp, cons
 	c->binned = false;
 	c->halo_valid = false;
 	c->forces_valid = false;
+	c->msl_pk_fresh = c->vl_ready && a.pk != nullptr;
 	return LS1HIP_OK;
 }
 
@@ -772,6 +788,7 @@ static int msl_build(ls1hip_ctx* c) {
 	HIPCHK(c, hipGetLastError());
 	c->vl_builds++;
 	c->vl_all_regular = false;
+	c->msl_pk_fresh = false;  // new order of the owned molecules
 	return LS1HIP_OK;
 }
 
@@ -866,6 +883,7 @@ static int forces_list_impl(ls1hip_ctx* c, int which, double dt, bool post_kick,
 		c->vl_bound_pending = true;
 		c->halo_valid = false;
 		c->forces_valid = false;
+		c->msl_pk_fresh = false;
 		c->vl_steps++;
 	} else {
 		c->forces_valid = true;

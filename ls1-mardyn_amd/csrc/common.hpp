@@ -30,6 +30,25 @@ extern __attribute__((weak)) const int ls1hip_variant_marker;
 
 namespace ls1 {
 
+// The 64-byte per-step record of the multi-site pair-stream force pass (kernels_force_mslist.hip): {x, y, z, q0, q1, q2, q3
+// (normalised once per molecule and step: FullMolecule::setupSoACache normalises q before rotating, FullMolecule.cpp:720), component
+// id}.  Written by k_msl_pack and by the rigid-body kick + drift passes (IntegArgs::pk) — ONE body, contraction off, so that the
+// record is the same bits whichever pass wrote it.
+__device__ __forceinline__ void msl_write_record(double* __restrict__ pk, uint32_t p, double x, double y, double z, double q0, double q1,
+												  double q2, double q3, bool with_rot, int cid) {
+#pragma clang fp contract(off)
+	double w = 1., qx = 0., qy = 0., qz = 0.;
+	if (with_rot) {
+		const double inv = 1. / sqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+		w = q0 * inv; qx = q1 * inv; qy = q2 * inv; qz = q3 * inv;
+	}
+	double2* const rec = reinterpret_cast<double2*>(pk + (size_t)8 * p);
+	rec[0] = make_double2(x, y);
+	rec[1] = make_double2(z, w);
+	rec[2] = make_double2(qx, qy);
+	rec[3] = make_double2(qz, __hiloint2double(0, cid));
+}
+
 struct MolSoA {  // one set of state arrays (two sets exist: the rebin gathers from one into the other)
 	double *x, *y, *z, *vx, *vy, *vz;
 	double *q0, *q1, *q2, *q3, *Dx, *Dy, *Dz;  // only allocated when the component set rotates
@@ -242,6 +261,7 @@ struct ls1hip_ctx {
 	uint32_t* d_msl_scratch = nullptr;  // [msl_capture_cap()][msl_stride]: hits captured by the count kernel
 	uint16_t* d_msl_mcnt = nullptr;     // [msl_stride]: hits per molecule
 	double* d_msl_pk = nullptr;         // [msl_stride][8]: packed per-step state of the owned molecules (k_msl_pack)
+	bool msl_pk_fresh = false;          // ... and it holds the CURRENT positions / orientations (written by the last kick + drift pass)
 	size_t msl_stride = 0;
 	size_t msl_groups_cap = 0, msl_pairs_cap = 0;
 	unsigned long long msl_pairs = 0;  // pairs of the current lists (incl. padding)
@@ -382,7 +402,7 @@ void launch_msl_count(const ForceParams& p, uint32_t* grp_cnt, uint32_t* off, ui
 void launch_msl_fill(const ForceParams& p, const uint32_t* off, const uint32_t* hsrc, const uint8_t* hdir, uint32_t* out_j,
 					 uint8_t* out_il, int ncomp, const uint32_t* scratch, const uint16_t* mcnt, uint32_t stride, hipStream_t s);
 bool launch_force_ms_list(const ForceParams& p, bool has_rot, bool lj_only, bool linear, int ncomp, const uint32_t* off, const uint32_t* pj, const uint8_t* pil,
-						  const double* shift27, double* pk, hipStream_t s, uint32_t* nblocks, size_t partials_cap);
+						  const double* shift27, double* pk, hipStream_t s, uint32_t* nblocks, size_t partials_cap, bool pk_fresh = false);
 // kin_in_slot1: the partials' slot 1 carries sum m v^2 of a fused force + integration pass (goes to cnt->kin[0], not to
 // the macroscopic sums); log (may be null): the step-log row {U_pot, virial, sum m v^2, sum I w^2, N, rotDOF} to refresh
 struct ReduceMode {
@@ -419,6 +439,10 @@ struct IntegArgs {
 	int pre_scale = 0;
 	double pre_bt = 1., pre_br = 1.;
 	double pre_bt_c[MAXC], pre_br_c[MAXC];
+	// multi-site neighbour lists: a kick + drift pass of rotating molecules also writes the packed per-step record of the pair-stream
+	// force pass (msl_write_record) — the separate k_msl_pack pass over the molecules (0.27 ms at 10^7) is then skipped
+	double* pk = nullptr;
+	int pk_ncomp = 1;
 };
 // kinetic sums per COMPONENT of the current velocities / angular momenta: out[c][4] = {sum m v^2, sum I w^2, N, rotational DOF}
 // (the host folds components into thermostats: Leapfrog.cpp:84-104, Domain::getThermostat)

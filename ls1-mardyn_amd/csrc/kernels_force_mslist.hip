@@ -283,17 +283,8 @@ __global__ void __launch_bounds__(256) k_msl_pack(ForceParams P, double* __restr
 	const uint32_t n_real = P.n_fixed ? P.n_fixed : P.cnt->n_real;
 	const uint32_t p = blockIdx.x * 256u + threadIdx.x;
 	if (p >= n_real) return;
-	double w = 1., x = 0., y = 0., z = 0.;
-	if (with_rot) {
-		w = P.q0[p]; x = P.q1[p]; y = P.q2[p]; z = P.q3[p];
-		const double inv = 1. / sqrt(w * w + x * x + y * y + z * z);
-		w *= inv; x *= inv; y *= inv; z *= inv;
-	}
-	double2* const rec = reinterpret_cast<double2*>(pk + (size_t)8 * p);
-	rec[0] = make_double2(P.x[p], P.y[p]);
-	rec[1] = make_double2(P.z[p], w);
-	rec[2] = make_double2(x, y);
-	rec[3] = make_double2(z, __hiloint2double(0, ncomp > 1 ? P.cid[p] : 0));
+	msl_write_record(pk, p, P.x[p], P.y[p], P.z[p], with_rot ? P.q0[p] : 1., with_rot ? P.q1[p] : 0., with_rot ? P.q2[p] : 0.,
+					 with_rot ? P.q3[p] : 0., with_rot != 0, ncomp > 1 ? P.cid[p] : 0);
 }
 
 // ---- REUSE: forces from the pair stream, one wave per group ----------------------------------------------------------------------
@@ -517,12 +508,13 @@ void launch_msl_fill(const ForceParams& p, const uint32_t* off, const uint32_t* 
 }
 
 bool launch_force_ms_list(const ForceParams& p, bool has_rot, bool lj_only, bool linear, int ncomp, const uint32_t* off, const uint32_t* pj, const uint8_t* pil,
-						  const double* shift27, double* pk, hipStream_t s, uint32_t* nblocks, size_t partials_cap) {
+						  const double* shift27, double* pk, hipStream_t s, uint32_t* nblocks, size_t partials_cap, bool pk_fresh) {
 	const uint32_t ng = msl_groups(p.n_real_cap);
 	if ((size_t)ng > partials_cap || p.which != 0) return false;
 	*nblocks = ng;
 	if (ng == 0) return true;
-	hipLaunchKernelGGL(k_msl_pack, dim3((p.n_real_cap + 255u) / 256u), dim3(256), 0, s, p, pk, has_rot ? 1 : 0, ncomp);
+	// (pk_fresh: the last rigid-body kick + drift pass wrote the records of the current state itself)
+	if (!pk_fresh) hipLaunchKernelGGL(k_msl_pack, dim3((p.n_real_cap + 255u) / 256u), dim3(256), 0, s, p, pk, has_rot ? 1 : 0, ncomp);
 	if (has_rot && lj_only && linear) hipLaunchKernelGGL((k_force_ms_list<true, true, true>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);
 	else if (has_rot && lj_only) hipLaunchKernelGGL((k_force_ms_list<true, true>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);
 	else if (has_rot) hipLaunchKernelGGL((k_force_ms_list<true, false>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);

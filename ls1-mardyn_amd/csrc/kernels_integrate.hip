@@ -55,9 +55,10 @@ __global__ void __launch_bounds__(ITPB) k_kick_drift(IntegArgs a) {
 	a.mol.vx[p] = vx;
 	a.mol.vy[p] = vy;
 	a.mol.vz[p] = vz;
-	a.mol.x[p] += dt * vx;
-	a.mol.y[p] += dt * vy;
-	a.mol.z[p] += dt * vz;
+	const double xn = a.mol.x[p] + dt * vx, yn = a.mol.y[p] + dt * vy, zn = a.mol.z[p] + dt * vz;
+	a.mol.x[p] = xn;
+	a.mol.y[p] = yn;
+	a.mol.z[p] = zn;
 	v2 = vx * vx + vy * vy + vz * vz;
 	if (HAS_ROT) {
 		double q[4] = {a.mol.q0[p], a.mol.q1[p], a.mol.q2[p], a.mol.q3[p]};
@@ -79,13 +80,16 @@ __global__ void __launch_bounds__(ITPB) k_kick_drift(IntegArgs a) {
 		q_diff(qh, w, dq);
 		for (int k = 0; k < 4; ++k) q[k] += dq[k] * dt;
 		qcorr = 1. / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-		a.mol.q0[p] = q[0] * qcorr;
-		a.mol.q1[p] = q[1] * qcorr;
-		a.mol.q2[p] = q[2] * qcorr;
-		a.mol.q3[p] = q[3] * qcorr;
+		const double qs0 = q[0] * qcorr, qs1 = q[1] * qcorr, qs2 = q[2] * qcorr, qs3 = q[3] * qcorr;
+		a.mol.q0[p] = qs0;
+		a.mol.q1[p] = qs1;
+		a.mol.q2[p] = qs2;
+		a.mol.q3[p] = qs3;
 		a.mol.Dx[p] = D.x;
 		a.mol.Dy[p] = D.y;
 		a.mol.Dz[p] = D.z;
+		// the record of the pair-stream force pass, from the values just stored (what k_msl_pack would read back)
+		if (a.pk) msl_write_record(a.pk, p, xn, yn, zn, qs0, qs1, qs2, qs3, true, a.pk_ncomp > 1 ? c : 0);
 	}
 	}
 	if (a.vmax_part) block_vmax(v2, a.vmax_part);  // every thread of the workgroup arrives here (one barrier inside)
@@ -114,9 +118,10 @@ __global__ void __launch_bounds__(ITPB) k_kick_then_kick_drift(IntegArgs a) {
 	a.mol.vy[p] = vy;
 	a.mol.vz[p] = vz;
 	v2 = vx * vx + vy * vy + vz * vz;
-	a.mol.x[p] += dt * vx;
-	a.mol.y[p] += dt * vy;
-	a.mol.z[p] += dt * vz;
+	const double xn = a.mol.x[p] + dt * vx, yn = a.mol.y[p] + dt * vy, zn = a.mol.z[p] + dt * vz;
+	a.mol.x[p] = xn;
+	a.mol.y[p] = yn;
+	a.mol.z[p] = zn;
 	if (HAS_ROT) {
 		double q[4] = {a.mol.q0[p], a.mol.q1[p], a.mol.q2[p], a.mol.q3[p]};
 		const double Mx = a.frc.Mx[p], My = a.frc.My[p], Mz = a.frc.Mz[p];
@@ -137,13 +142,16 @@ __global__ void __launch_bounds__(ITPB) k_kick_then_kick_drift(IntegArgs a) {
 		q_diff(qh, w, dq);
 		for (int k = 0; k < 4; ++k) q[k] += dq[k] * dt;
 		qcorr = 1. / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-		a.mol.q0[p] = q[0] * qcorr;
-		a.mol.q1[p] = q[1] * qcorr;
-		a.mol.q2[p] = q[2] * qcorr;
-		a.mol.q3[p] = q[3] * qcorr;
+		const double qs0 = q[0] * qcorr, qs1 = q[1] * qcorr, qs2 = q[2] * qcorr, qs3 = q[3] * qcorr;
+		a.mol.q0[p] = qs0;
+		a.mol.q1[p] = qs1;
+		a.mol.q2[p] = qs2;
+		a.mol.q3[p] = qs3;
 		a.mol.Dx[p] = D.x;
 		a.mol.Dy[p] = D.y;
 		a.mol.Dz[p] = D.z;
+		// the record of the pair-stream force pass, from the values just stored (what k_msl_pack would read back)
+		if (a.pk) msl_write_record(a.pk, p, xn, yn, zn, qs0, qs1, qs2, qs3, true, a.pk_ncomp > 1 ? c : 0);
 	}
 	}
 	if (a.vmax_part) block_vmax(v2, a.vmax_part);

@@ -30,9 +30,8 @@ extern __attribute__((weak)) const int ls1hip_variant_marker;
 
 namespace ls1 {
 
-// The 64-byte per-step record of the multi-site pair-stream force pass (kernels_force_mslist.hip): {x, y, z, q0, q1, q2, q3
-// (normalised once per molecule and step: FullMolecule::setupSoACache normalises q before rotating, FullMolecule.cpp:720), component
-// id}.  Written by k_msl_pack and by the rigid-body kick + drift passes (IntegArgs::pk) — ONE body, contraction off, so that the
+// The 64-byte per-step record of the multi-site pair-stream force pass (kernels_force_mslist.hip): {x, y, z, component id, q0, q1,
+// q2, q3 (normalised once per molecule and step: FullMolecule::setupSoACache normalises q before rotating, FullMolecule.cpp:720)}.  Written by k_msl_pack and by the rigid-body kick + drift passes (IntegArgs::pk) — ONE body, contraction off, so that the
 // record is the same bits whichever pass wrote it.
 __device__ __forceinline__ void msl_write_record(double* __restrict__ pk, uint32_t p, double x, double y, double z, double q0, double q1,
 												  double q2, double q3, bool with_rot, int cid) {
@@ -44,9 +43,9 @@ __device__ __forceinline__ void msl_write_record(double* __restrict__ pk, uint32
 	}
 	double2* const rec = reinterpret_cast<double2*>(pk + (size_t)8 * p);
 	rec[0] = make_double2(x, y);
-	rec[1] = make_double2(z, w);
-	rec[2] = make_double2(qx, qy);
-	rec[3] = make_double2(qz, __hiloint2double(0, cid));
+	rec[1] = make_double2(z, __hiloint2double(0, cid));  // (the first 32 bytes are all the cutoff filter of the force pass reads)
+	rec[2] = make_double2(w, qx);
+	rec[3] = make_double2(qy, qz);
 }
 
 struct MolSoA {  // one set of state arrays (two sets exist: the rebin gathers from one into the other)

@@ -57,12 +57,22 @@ namespace ls1 {
 constexpr int MSG = 128;                    // molecules per group (= per wave of the force pass)
 constexpr uint32_t MSL_IDX = 0x07ffffffu;  // pair entry: bits 0-26 molecule index, bits 27-31 shift index (13 = none)
 constexpr int MSL_MAXT = MAXC * MAXC;       // component pairs
+constexpr uint32_t MSQ = 256;               // force pass: entries of a wave's queue of pairs inside the cutoff (< 64 left over + 128 of two trips)
+static_assert(MSG <= 128 && MAXC * MAXC <= 512, "queue entry: 7 bits local molecule, 9 bits component pair");
 
 int msl_group_size() { return MSG; }
 
 __device__ __forceinline__ uint32_t msl_wave_sum(uint32_t v) {
 	for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
 	return v;
+}
+// Orders the LDS accesses of the ONE wave of a workgroup (queue writes of some lanes, reads by others): LDS instructions of a
+// wave execute in order, so no instruction is needed — only the compiler must not move them.  (__syncthreads() here would also
+// wait for every global load in flight, vmcnt(0): exactly the prefetched gathers the filter pipeline keeps behind the bodies.)
+__device__ __forceinline__ void msl_wave_lds_order() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 // ---- run accumulation (LJ-only sets) ---------------------------------------------------------------------------------------
 // The pairs of a block are sorted by (component pair, local molecule): the lanes of a trip that feed the SAME accumulator are
@@ -297,15 +307,25 @@ __global__ void __launch_bounds__(256) k_msl_pack(ForceParams P, double* __restr
 template <bool WITH_ROT, bool LJ_ONLY, bool LINEAR = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_force_ms_list(ForceParams P, const uint32_t* __restrict__ off, const uint32_t* __restrict__ pj,
 													  const uint8_t* __restrict__ pil, const double* __restrict__ shift27,
-													  const double* __restrict__ pk, const CompTable* __restrict__ ctab) {
+													  const double* __restrict__ pk, const CompTable* __restrict__ ctab, uint32_t ngroups) {
 	__shared__ double sr[3][MSG];
 	__shared__ double sq[WITH_ROT ? 4 : 1][MSG];
-	__shared__ int sci[MSG];
+	__shared__ uint8_t sci[MSG];
 	__shared__ double acc[WITH_ROT ? 6 : 3][MSG];
 	__shared__ double ssh[27 * 3];
+	__shared__ uint32_t sque_e[MSQ];
+	__shared__ uint16_t sque_m[MSQ];
 	const int lane = threadIdx.x;
 	const uint32_t n_real = P.n_fixed ? P.n_fixed : P.cnt->n_real;
-	const uint32_t p0 = blockIdx.x * MSG;
+	// workgroups are dealt round-robin to the 8 XCDs (each with its own L2): XCD x takes the x-th CHUNK of consecutive groups, so
+	// that neighbouring groups — which gather the same partners — share one L2
+#if defined(LS1_BUILD_VARIANT) && defined(LS1_X_NO_XCD_CHUNKS)
+	const uint32_t grp = blockIdx.x;  // (A/B: consecutive groups on different XCDs)
+#else
+	const uint32_t chunk = gridDim.x >> 3, grp = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+#endif
+	if (grp >= ngroups) return;
+	const uint32_t p0 = grp * MSG;
 	// the component table as its OWN restrict-qualified kernel argument: its loads are then provably not clobbered by the force
 	// stores and, the component indices being wave-uniform, become scalar loads (through P.ct they were ~60 dependent vector
 	// loads per trip — that, not the arithmetic, was the trip time of the first versions)
@@ -321,12 +341,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
 		sr[1][k] = d0.y;
 		sr[2][k] = d1.x;
 		if (WITH_ROT) {
-			sq[0][k] = d1.y;
-			sq[1][k] = d2.x;
-			sq[2][k] = d2.y;
-			sq[3][k] = d3.x;
+			sq[0][k] = d2.x;
+			sq[1][k] = d2.y;
+			sq[2][k] = d3.x;
+			sq[3][k] = d3.y;
 		}
-		sci[k] = (ok && ncomp > 1) ? (int)__double2loint(d3.y) : 0;
+		sci[k] = (uint8_t)((ok && ncomp > 1) ? __double2loint(d1.y) : 0);
 		for (int a = 0; a < (WITH_ROT ? 6 : 3); ++a) acc[a][k] = 0.;
 	}
 	for (int k = lane; k < 81; k += 64) ssh[k] = shift27[k];
@@ -337,17 +357,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
 	a.M = {0., 0., 0.};
 	a.Vi = {0., 0., 0.};
 	a.u6 = a.uX = a.rf = a.vir = 0.;
-	const uint32_t b0 = off[blockIdx.x], b1 = off[blockIdx.x + 1];
-	// Software pipeline, two trips deep: the pair record of trip t + 2 and the partner's packed state of trip t + 1 are requested
-	// before the bodies of trip t run — the gathers go through L2 / HBM, and at two waves per SIMD (the register budget of the
-	// molecule-pair body) nothing else hides their latency.  The partner's state is ONE 64-byte record (k_msl_pack): gathered
-	// from eight separate arrays every lane pulled eight cache lines through the L1 for 60 useful bytes, and the L2 -> L1 fill
-	// rate (64 B / clk / CU), not the arithmetic, set the pace (first version: VALU 41 % busy).
-	// (the loaded words are carried RAW into the next trip: any arithmetic on them here — the periodic shift, a conversion —
-	// would make the wave wait for the gather before the bodies of the current trip instead of behind them)
-	struct Partner {
-		uint32_t il, sh;
-		double2 d0, d1, d2, d3;
+	const uint32_t b0 = off[grp], b1 = off[grp + 1];
+	// Two stages per wave.  FILTER: a trip of 64 listed pairs gathers the first 32 bytes of the partners' records (position,
+	// component id), applies the periodic shift and the centre-of-mass cutoff, and appends the pairs INSIDE the cutoff to a ring
+	// queue in LDS (order kept: component pair, local molecule).  BODIES: whenever the queue holds 64 pairs, or a complete run
+	// of one component pair, those lanes gather the full 64-byte records and evaluate the molecule pair.  Every lane of a body
+	// pass has work and one component pair — scalar component indices, no divergence — whereas a lane per LISTED pair idles
+	// for the pairs of the skin ((r_c / (r_c + skin))^3 = 70-78 % inside) and a trip of 64 that straddles two component pairs
+	// costs two passes (five components, 128 molecules: ~120 listed pairs per component pair — 2.9 passes for 1.5 full ones).
+	// Filter pipeline, two trips deep: the pair words of trip t + 2 and the partners' positions of trip t + 1 are requested before
+	// trip t is looked at; they stay in flight behind the body passes.  (The loaded words are carried RAW into the next trip: any
+	// arithmetic on them would make the wave wait for the gather before the bodies instead of behind them.)
+	struct Cand {
+		uint32_t e, il;
+		double2 d0, d1;
 	};
 	auto load_record = [&](uint32_t b, uint32_t& e, uint32_t& il) {
 		e = 0u | (13u << 27);
@@ -357,111 +380,132 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
 			il = pil[b + lane];
 		}
 	};
-	auto load_partner = [&](uint32_t e, uint32_t il) {
-		Partner n;
+	auto load_cand = [&](uint32_t e, uint32_t il) {
+		Cand n;
 		const double2* const rec = reinterpret_cast<const double2*>(pk + (size_t)8 * (e & MSL_IDX));
 		n.d0 = rec[0];
 		n.d1 = rec[1];
-		n.d2 = rec[2];
-		n.d3 = rec[3];
+		n.e = e;
 		n.il = il;
-		n.sh = e >> 27;
 		return n;
 	};
-	uint32_t e2, il2;
-	load_record(b0, e2, il2);
-	Partner nxt = load_partner(e2, il2);
-	load_record(b0 + 64u, e2, il2);
-	for (uint32_t b = b0; b < b1; b += 64u) {
-		const Partner raw = nxt;
-		nxt = load_partner(e2, il2);          // trip t + 1 (a padding record past the end: molecule 0, never evaluated)
-		load_record(b + 128u, e2, il2);        // trip t + 2
-		struct {
-			uint32_t il;
-			double x, y, z, q0, q1, q2, q3;
-			int cj;
-		} cur;
-		cur.il = raw.il;
-		cur.x = raw.d0.x + ssh[3 * raw.sh];
-		cur.y = raw.d0.y + ssh[3 * raw.sh + 1];
-		cur.z = raw.d1.x + ssh[3 * raw.sh + 2];
-		cur.q0 = raw.d1.y; cur.q1 = raw.d2.x; cur.q2 = raw.d2.y; cur.q3 = raw.d3.x;
-		cur.cj = (int)__double2loint(raw.d3.y);
-		const bool valid = cur.il != 0xffu;
-		const uint32_t k = valid ? cur.il : 0u;
-		const V3 ri = {sr[0][k], sr[1][k], sr[2][k]};
-		const V3 rj = {cur.x, cur.y, cur.z};
-		const V3 drm = ri - rj;
-		const double dd = dot(drm, drm);
-		const bool in = valid && dd < rc2 && dd != 0.;
-		int tkey = 0;
-		using RotT = typename std::conditional<LINEAR, RotAxis, Rot>::type;
-		RotT Ri, Rj;
-		if constexpr (LINEAR) Ri = Rj = rot_axis_of(1., 0., 0., 0.);
-		else Ri = Rj = rot_of(1., 0., 0., 0.);
-		if (in) {
-			if (ncomp > 1) tkey = sci[k] * MAXC + cur.cj;
-			if (WITH_ROT) {
-				if constexpr (LINEAR) {
-					Ri = rot_axis_of(sq[0][k], sq[1][k], sq[2][k], sq[3][k]);
-					Rj = rot_axis_of(cur.q0, cur.q1, cur.q2, cur.q3);  // (normalised by k_msl_pack)
-				} else {
-					Ri = rot_of(sq[0][k], sq[1][k], sq[2][k], sq[3][k]);
-					Rj = rot_of(cur.q0, cur.q1, cur.q2, cur.q3);  // (normalised by k_msl_pack)
-				}
+	// LJ-only sets (cheap bodies: the gathers are what has to be hidden): an iteration filters TWO trips (two candidates per lane)
+	// before it drains the queue — 128 listed pairs leave >= 64 inside the cutoff, so that (nearly) every iteration runs a body
+	// pass between the issue of the next iteration's gathers and their use.  The multipole body has no registers to spare for that.
+	constexpr int NC = LJ_ONLY ? 2 : 1;
+	uint32_t e2[NC], il2[NC];
+	Cand nxt[NC];
+#pragma unroll
+	for (int h = 0; h < NC; ++h) {
+		load_record(b0 + 64u * h, e2[h], il2[h]);
+		nxt[h] = load_cand(e2[h], il2[h]);
+	}
+#pragma unroll
+	for (int h = 0; h < NC; ++h) load_record(b0 + 64u * NC + 64u * h, e2[h], il2[h]);
+	uint32_t qhead = 0, qn = 0;  // wave-uniform: ring of MSQ entries {pair word; local molecule | component pair << 7}
+	for (uint32_t b = b0;; b += 64u * NC) {
+		const bool more = b < b1;
+		if (more) {
+			Cand raw[NC];
+#pragma unroll
+			for (int h = 0; h < NC; ++h) {
+				raw[h] = nxt[h];
+				nxt[h] = load_cand(e2[h], il2[h]);  // the next iteration's trips (padding records past the end: molecule 0, never queued)
 			}
+#pragma unroll
+			for (int h = 0; h < NC; ++h) load_record(b + 128u * NC + 64u * h, e2[h], il2[h]);  // the trips after those
+#pragma unroll
+			for (int h = 0; h < NC; ++h) {
+				const bool valid = raw[h].il != 0xffu;
+				const uint32_t k = valid ? raw[h].il : 0u, sh = raw[h].e >> 27;
+				const V3 drm = {sr[0][k] - (raw[h].d0.x + ssh[3 * sh]), sr[1][k] - (raw[h].d0.y + ssh[3 * sh + 1]),
+								sr[2][k] - (raw[h].d1.x + ssh[3 * sh + 2])};
+				const double dd = dot(drm, drm);
+				const bool in = valid && dd < rc2 && dd != 0.;
+				const uint32_t key = ncomp > 1 ? (uint32_t)((int)sci[k] * MAXC + __double2loint(raw[h].d1.y)) : 0u;
+				const unsigned long long m = __ballot(in);
+				const uint32_t at = (qhead + qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) & (MSQ - 1);
+				if (in) {
+					sque_e[at] = raw[h].e;
+					sque_m[at] = (uint16_t)(raw[h].il | (key << 7));
+				}
+				qn += (uint32_t)__popcll(m);
+			}
+			msl_wave_lds_order();  // the queue writes above before the reads below
 		}
-		a.F = {0., 0., 0.};
-		a.M = {0., 0., 0.};
-		// one component pair at a time, with wave-uniform component indices (the blocks are sorted by component pair: a trip
-		// normally holds one or two of them)
-		unsigned long long todo = __ballot(in);
-		while (todo) {
-			const int first = __ffsll((long long)todo) - 1;
-			const int t = __builtin_amdgcn_readlane(tkey, first);
-			const bool mine = in && tkey == t;
-			if (mine) {
-				// every active lane holds the same component pair: read it back as a SCALAR inside the branch (written as t / MAXC
-				// the compiler substitutes the lane's own key — it knows tkey == t here — and every table load behind it becomes a
-				// per-lane vector load with its own latency chain)
-				const int ci_u = __builtin_amdgcn_readfirstlane(tkey) / MAXC, cj_u = __builtin_amdgcn_readfirstlane(tkey) % MAXC;
+		while (qn >= 64u || (!more && qn > 0u)) {
+			const uint32_t qat = (qhead + (uint32_t)lane) & (MSQ - 1);
+			const uint32_t ent_e = sque_e[qat], ent_m = sque_m[qat];
+			const uint32_t key0 = __builtin_amdgcn_readfirstlane(ent_m >> 7);
+			// the leading run of one component pair among the first 64 entries (the stream is sorted: equal keys are contiguous)
+			const uint32_t cnt = (uint32_t)__popcll(__ballot((uint32_t)lane < qn && (ent_m >> 7) == key0));
+			const bool act = (uint32_t)lane < cnt;
+			const uint32_t k = act ? (ent_m & 0x7fu) : 0u, sh = act ? (ent_e >> 27) : 13u;
+			const double2* const rec = reinterpret_cast<const double2*>(pk + (size_t)8 * (act ? (ent_e & MSL_IDX) : 0u));
+			const double2 d0 = rec[0], d1 = rec[1];
+			double2 d2 = make_double2(0., 0.), d3 = d2;
+			if (WITH_ROT) {
+				d2 = rec[2];
+				d3 = rec[3];
+			}
+			const V3 ri = {sr[0][k], sr[1][k], sr[2][k]};
+			const V3 rj = {d0.x + ssh[3 * sh], d0.y + ssh[3 * sh + 1], d1.x + ssh[3 * sh + 2]};
+			const V3 drm = ri - rj;
+			const double dd = dot(drm, drm);
+			using RotT = typename std::conditional<LINEAR, RotAxis, Rot>::type;
+			a.F = {0., 0., 0.};
+			a.M = {0., 0., 0.};
+			if (act) {
+				RotT Ri, Rj;
+				if constexpr (LINEAR) {
+					Ri = WITH_ROT ? rot_axis_of(sq[0][k], sq[1][k], sq[2][k], sq[3][k]) : rot_axis_of(1., 0., 0., 0.);
+					Rj = WITH_ROT ? rot_axis_of(d2.x, d2.y, d3.x, d3.y) : rot_axis_of(1., 0., 0., 0.);  // (normalised by the writer of the record)
+				} else {
+					Ri = WITH_ROT ? rot_of(sq[0][k], sq[1][k], sq[2][k], sq[3][k]) : rot_of(1., 0., 0., 0.);
+					Rj = WITH_ROT ? rot_of(d2.x, d2.y, d3.x, d3.y) : rot_of(1., 0., 0., 0.);
+				}
+				// one component pair for the whole pass: scalar indices, parameter tables through scalar loads
+				const int ci_u = (int)(key0 / (uint32_t)MAXC), cj_u = (int)(key0 % (uint32_t)MAXC);
 				mol_pair<false, ConstCompTable, LJ_ONLY, RotT>(ct, ci_u, ri, Ri, cj_u, rj, Rj, drm, dd < rclj2, 0.5, a);
 			}
-			todo &= ~__ballot(mine);
-		}
 #if defined(LS1_BUILD_VARIANT) && defined(LS1_X_NO_RUNSUM)
-		constexpr bool RUNSUM = false;  // (A/B: one ds_add_f64 per pair, the round-3 form)
+			constexpr bool RUNSUM = false;  // (A/B: one ds_add_f64 per pair, the round-3 form)
 #else
-		constexpr bool RUNSUM = LJ_ONLY;
+			constexpr bool RUNSUM = LJ_ONLY;
 #endif
-		if constexpr (RUNSUM) {
-			// run accumulation (see msl_run_sums): every lane takes part in the row shifts; out-of-range and padding lanes carry
-			// zeros, padding lanes (il = 0xff) share the key -1 and never store
-			double val[WITH_ROT ? 6 : 3];
-			val[0] = in ? a.F.x : 0.;
-			val[1] = in ? a.F.y : 0.;
-			val[2] = in ? a.F.z : 0.;
-			if constexpr (WITH_ROT) {
-				val[3] = in ? a.M.x : 0.;
-				val[4] = in ? a.M.y : 0.;
-				val[5] = in ? a.M.z : 0.;
-			}
-			const int key = valid ? (int)k : -1;
-			const bool tail = msl_run_sums(key, val);
-			if (tail && valid) {
+			if constexpr (RUNSUM) {
+				// run accumulation (see msl_run_sums): every lane takes part in the row shifts; lanes past the run carry zeros, share
+				// the key -1 and never store
+				double val[WITH_ROT ? 6 : 3];
+				val[0] = act ? a.F.x : 0.;
+				val[1] = act ? a.F.y : 0.;
+				val[2] = act ? a.F.z : 0.;
+				if constexpr (WITH_ROT) {
+					val[3] = act ? a.M.x : 0.;
+					val[4] = act ? a.M.y : 0.;
+					val[5] = act ? a.M.z : 0.;
+				}
+				const int rkey = act ? (int)k : -1;
+				const bool tail = msl_run_sums(rkey, val);
+				if (tail && act) {
 #pragma unroll
-				for (int c = 0; c < (WITH_ROT ? 6 : 3); ++c) unsafeAtomicAdd(&acc[c][k], val[c]);
+					for (int c = 0; c < (WITH_ROT ? 6 : 3); ++c) unsafeAtomicAdd(&acc[c][k], val[c]);
+				}
+			} else if (act) {
+				unsafeAtomicAdd(&acc[0][k], a.F.x);
+				unsafeAtomicAdd(&acc[1][k], a.F.y);
+				unsafeAtomicAdd(&acc[2][k], a.F.z);
+				if (WITH_ROT) {
+					unsafeAtomicAdd(&acc[3][k], a.M.x);
+					unsafeAtomicAdd(&acc[4][k], a.M.y);
+					unsafeAtomicAdd(&acc[5][k], a.M.z);
+				}
 			}
-		} else if (in) {
-			unsafeAtomicAdd(&acc[0][k], a.F.x);
-			unsafeAtomicAdd(&acc[1][k], a.F.y);
-			unsafeAtomicAdd(&acc[2][k], a.F.z);
-			if (WITH_ROT) {
-				unsafeAtomicAdd(&acc[3][k], a.M.x);
-				unsafeAtomicAdd(&acc[4][k], a.M.y);
-				unsafeAtomicAdd(&acc[5][k], a.M.z);
-			}
+			qhead = (qhead + cnt) & (MSQ - 1);
+			qn -= cnt;
+			msl_wave_lds_order();  // the queue reads above before the next trip's writes
 		}
+		if (!more) break;
 	}
 	__syncthreads();
 	for (int k = lane; k < MSG; k += 64) {
@@ -479,7 +523,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
 	}
 	const double u6 = msl_wave_sum_d(a.u6), uX = msl_wave_sum_d(a.uX), rf = msl_wave_sum_d(a.rf), vir = msl_wave_sum_d(a.vir);
 	if (lane == 0) {
-		double* out = P.partials + (size_t)blockIdx.x * 4;
+		double* out = P.partials + (size_t)grp * 4;
 		out[0] = u6;
 		out[1] = uX;
 		out[2] = rf;
@@ -513,13 +557,14 @@ bool launch_force_ms_list(const ForceParams& p, bool has_rot, bool lj_only, bool
 	if ((size_t)ng > partials_cap || p.which != 0) return false;
 	*nblocks = ng;
 	if (ng == 0) return true;
+	const uint32_t grid = ((ng + 7u) >> 3) << 3;  // (8 chunks of consecutive groups, see the kernel)
 	// (pk_fresh: the last rigid-body kick + drift pass wrote the records of the current state itself)
 	if (!pk_fresh) hipLaunchKernelGGL(k_msl_pack, dim3((p.n_real_cap + 255u) / 256u), dim3(256), 0, s, p, pk, has_rot ? 1 : 0, ncomp);
-	if (has_rot && lj_only && linear) hipLaunchKernelGGL((k_force_ms_list<true, true, true>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);
-	else if (has_rot && lj_only) hipLaunchKernelGGL((k_force_ms_list<true, true>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);
-	else if (has_rot) hipLaunchKernelGGL((k_force_ms_list<true, false>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);
-	else if (lj_only) hipLaunchKernelGGL((k_force_ms_list<false, true>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);
-	else hipLaunchKernelGGL((k_force_ms_list<false, false>), dim3(ng), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct);
+	if (has_rot && lj_only && linear) hipLaunchKernelGGL((k_force_ms_list<true, true, true>), dim3(grid), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct, ng);
+	else if (has_rot && lj_only) hipLaunchKernelGGL((k_force_ms_list<true, true>), dim3(grid), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct, ng);
+	else if (has_rot) hipLaunchKernelGGL((k_force_ms_list<true, false>), dim3(grid), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct, ng);
+	else if (lj_only) hipLaunchKernelGGL((k_force_ms_list<false, true>), dim3(grid), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct, ng);
+	else hipLaunchKernelGGL((k_force_ms_list<false, false>), dim3(grid), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct, ng);
 	return true;
 }
 

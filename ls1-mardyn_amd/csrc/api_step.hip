@@ -167,6 +167,7 @@ static void fill_force_params(ls1hip_ctx* c, ForceParams& P, int which) {
 	P.vl_rec = c->d_vl_rec;
 	P.vl_ii = c->d_vl_ii;
 	P.vl_gi = c->d_vl_gi;
+	P.msl_gm = c->h_ct.ncomp > 1 ? c->d_msl_gm : nullptr;
 }
 
 static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
@@ -750,8 +751,11 @@ static int msl_build(ls1hip_ctx* c) {
 	if ((size_t)ng + 1 > c->msl_groups_cap) {
 		dfree(c->d_msl_cnt);
 		dfree(c->d_msl_off);
+		dfree(c->d_msl_gm);
 		c->msl_groups_cap = 0;
-		if ((rc = dalloc(c, &c->d_msl_cnt, (size_t)ng + 1)) || (rc = dalloc(c, &c->d_msl_off, (size_t)ng + 2))) return rc;
+		if ((rc = dalloc(c, &c->d_msl_cnt, (size_t)ng + 1)) || (rc = dalloc(c, &c->d_msl_off, (size_t)ng + 2)) ||
+			(rc = dalloc(c, &c->d_msl_gm, ((size_t)ng + 1) * 128)))
+			return rc;
 		c->msl_groups_cap = (size_t)ng + 1;
 	}
 	if (c->n_real > c->msl_stride) {
@@ -767,6 +771,7 @@ static int msl_build(ls1hip_ctx* c) {
 	}
 	ForceParams P;
 	fill_force_params(c, P, 0);
+	if (P.msl_gm) launch_msl_groups(P, c->d_msl_gm, c->h_ct.ncomp, c->stream);
 	launch_msl_count(P, c->d_msl_cnt, c->d_msl_off, c->d_msl_scratch, c->d_msl_mcnt, (uint32_t)c->msl_stride, c->stream);
 	HIPCHK(c, hipGetLastError());
 	// one host round trip per list build: the pair count sizes the stream

@@ -105,6 +105,9 @@ struct ForceParams {
 	uint32_t n_real_cap;  // launch bound (n_real is read from cnt for device-driven loops)
 	int which;         // 0 all, 1 inner cells, 2 boundary cells, 3 all non-halo cells (seam A)
 	uint32_t n_fixed;  // if != 0: number of molecules (overrides cnt->n_real; seam A)
+	// multi-site pair-stream lists: molecule of every group slot (groups sorted by component inside windows of 8 groups), nullptr =
+	// slot s is molecule s (one component)
+	const uint32_t* msl_gm = nullptr;
 	int count_pairs;
 	const uint32_t* brick_list;  // brick kernels: bricks of this pass (boundary), nullptr = all bricks / inner box
 	uint32_t n_list;
@@ -259,6 +262,7 @@ struct ls1hip_ctx {
 	uint8_t* d_msl_il = nullptr;
 	uint32_t* d_msl_scratch = nullptr;  // [msl_capture_cap()][msl_stride]: hits captured by the count kernel
 	uint16_t* d_msl_mcnt = nullptr;     // [msl_stride]: hits per molecule
+	uint32_t* d_msl_gm = nullptr;       // [groups * 128]: molecule of every group slot (k_msl_groups; several components only)
 	double* d_msl_pk = nullptr;         // [msl_stride][8]: packed per-step state of the owned molecules (k_msl_pack)
 	bool msl_pk_fresh = false;          // ... and it holds the CURRENT positions / orientations (written by the last kick + drift pass)
 	size_t msl_stride = 0;
@@ -396,6 +400,7 @@ bool launch_force_sites(const ForceParams& p, const CompTable& hct, bool with_vi
 int msl_group_size();
 uint32_t msl_groups(uint32_t n_real);
 int msl_capture_cap();  // hits per molecule the count kernel keeps for the fill kernel (scratch[k][stride])
+void launch_msl_groups(const ForceParams& p, uint32_t* gm, int ncomp, hipStream_t s);
 void launch_msl_count(const ForceParams& p, uint32_t* grp_cnt, uint32_t* off, uint32_t* scratch, uint16_t* mcnt, uint32_t stride,
 					  hipStream_t s);
 void launch_msl_fill(const ForceParams& p, const uint32_t* off, const uint32_t* hsrc, const uint8_t* hdir, uint32_t* out_j,

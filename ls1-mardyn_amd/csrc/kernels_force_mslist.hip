@@ -57,7 +57,6 @@ namespace ls1 {
 constexpr int MSG = 128;                    // molecules per group (= per wave of the force pass)
 constexpr uint32_t MSL_IDX = 0x07ffffffu;  // pair entry: bits 0-26 molecule index, bits 27-31 shift index (13 = none)
 constexpr int MSL_MAXT = MAXC * MAXC;       // component pairs
-constexpr uint32_t MSQ = 256;               // force pass: entries of a wave's queue of pairs inside the cutoff (< 64 left over + 128 of two trips)
 static_assert(MSG <= 128 && MAXC * MAXC <= 512, "queue entry: 7 bits local molecule, 9 bits component pair");
 
 int msl_group_size() { return MSG; }
@@ -161,12 +160,48 @@ __device__ __forceinline__ void msl_walk(const ForceParams& P, uint32_t p, doubl
 		}
 }
 
+// ---- BUILD 0 (several components): which molecule sits in which group slot -----------------------------------------------------
+// A body pass of the force kernel evaluates up to 64 pairs of ONE component pair; a group of 128 consecutive molecules of a
+// five-component mixture has 25 component pairs of ~95 pairs inside the cutoff each: two passes for 1.5 full ones.  Groups are
+// therefore formed inside WINDOWS of 8 groups (1024 consecutive molecules, cell order: a few rows of cells): the window's molecules
+// are sorted by component (stable), the groups are slices of 128 of that order — one or two components per group, runs of
+// ~300 pairs.  The state arrays keep their order; only the lists and the force pass go through this map (0xffffffff = empty slot).
+__device__ __forceinline__ uint32_t msl_slot(const ForceParams& P, uint32_t slot) { return P.msl_gm ? P.msl_gm[slot] : slot; }
+
+constexpr int MSW = 1024;  // slots per window
+__global__ void __launch_bounds__(MSW) k_msl_groups(ForceParams P, uint32_t* __restrict__ gm, int ncomp, uint32_t nslots) {
+	__shared__ uint32_t wcnt[MAXC][MSW / 64];
+	const uint32_t n_real = P.n_fixed ? P.n_fixed : P.cnt->n_real;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const uint32_t s0 = blockIdx.x * MSW, p = s0 + (uint32_t)tid;
+	const bool active = p < n_real;
+	const int c = active ? P.cid[p] : -1;
+	uint32_t rank = 0;
+	for (int k = 0; k < ncomp; ++k) {
+		const unsigned long long m = __ballot(c == k);
+		if (lane == 0) wcnt[k][wv] = (uint32_t)__popcll(m);
+		if (c == k) rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+	}
+	__syncthreads();
+	uint32_t at = rank, total = 0;
+	for (int k = 0; k < ncomp; ++k)
+		for (int w = 0; w < MSW / 64; ++w) {
+			const uint32_t n = wcnt[k][w];
+			total += n;
+			if (k < c || (k == c && w < wv)) at += n;
+		}
+	if (active) gm[s0 + at] = p;
+	if ((uint32_t)tid >= total && s0 + (uint32_t)tid < nslots) gm[s0 + (uint32_t)tid] = 0xffffffffu;
+}
+
 // ---- BUILD 1: pairs per group; the hits of every molecule are kept (first MSL_CAP of them) for the fill kernel ------------------
 constexpr int MSL_CAP = 32;  // captured hits per molecule: scratch[k][p], k < MSL_CAP (coalesced over p); more: the fill kernel walks again
 __global__ void __launch_bounds__(MSG) k_msl_count(ForceParams P, uint32_t* grp_cnt, uint32_t* __restrict__ scratch,
 												   uint16_t* __restrict__ mcnt, uint32_t stride) {
 	__shared__ uint32_t wsum[MSG / 64];
 	const uint32_t n_real = P.n_fixed ? P.n_fixed : P.cnt->n_real;
+	// (always in the order of the state arrays — the lanes of a wave walk the same cells; with several components the group sums are
+	// taken through the slot map afterwards, k_msl_group_sums)
 	const uint32_t p = blockIdx.x * MSG + threadIdx.x;
 	uint32_t cnt = 0;
 	if (p < n_real) {
@@ -177,6 +212,15 @@ __global__ void __launch_bounds__(MSG) k_msl_count(ForceParams P, uint32_t* grp_
 		mcnt[p] = (uint16_t)min(cnt, 0xffffu);
 	}
 	cnt = msl_wave_sum(cnt);
+	if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+	__syncthreads();
+	if (threadIdx.x == 0 && !P.msl_gm) grp_cnt[blockIdx.x] = wsum[0] + wsum[1];
+}
+__global__ void __launch_bounds__(MSG) k_msl_group_sums(ForceParams P, uint32_t* grp_cnt, const uint16_t* __restrict__ mcnt) {
+	__shared__ uint32_t wsum[MSG / 64];
+	const uint32_t n_real = P.n_fixed ? P.n_fixed : P.cnt->n_real;
+	const uint32_t p = P.msl_gm[blockIdx.x * MSG + threadIdx.x];
+	uint32_t cnt = msl_wave_sum(p < n_real ? (uint32_t)mcnt[p] : 0u);
 	if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
 	__syncthreads();
 	if (threadIdx.x == 0) grp_cnt[blockIdx.x] = wsum[0] + wsum[1];
@@ -235,7 +279,7 @@ __global__ void __launch_bounds__(MSG) k_msl_fill(ForceParams P, const uint32_t*
 	__shared__ uint32_t wsum[2];
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const uint32_t n_real = P.n_fixed ? P.n_fixed : P.cnt->n_real;
-	const uint32_t p = blockIdx.x * MSG + (uint32_t)tid;
+	const uint32_t p = msl_slot(P, blockIdx.x * MSG + (uint32_t)tid);
 	const bool active = p < n_real;
 	const int ntypes = ncomp * ncomp;
 	const int ci = (active && ncomp > 1) ? P.cid[p] : 0;
@@ -313,6 +357,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
 	__shared__ uint8_t sci[MSG];
 	__shared__ double acc[WITH_ROT ? 6 : 3][MSG];
 	__shared__ double ssh[27 * 3];
+	// queue of the pairs inside the cutoff: < 64 left over + 64 per filtered trip (NC trips per iteration, see below)
+	constexpr int NC = LJ_ONLY ? 2 : 1;
+	constexpr uint32_t MSQ = 128u * NC;
 	__shared__ uint32_t sque_e[MSQ];
 	__shared__ uint16_t sque_m[MSQ];
 	const int lane = threadIdx.x;
@@ -333,7 +380,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
 	ConstCompTable& ct = *(ConstCompTable*)(uintptr_t)ctab;
 	const int ncomp = ct.ncomp;
 	for (int k = lane; k < MSG; k += 64) {
-		const uint32_t p = p0 + (uint32_t)k;
+		const uint32_t p = msl_slot(P, p0 + (uint32_t)k);
 		const bool ok = p < n_real;
 		const double2* const rec = reinterpret_cast<const double2*>(pk + (size_t)8 * (ok ? p : 0u));
 		const double2 d0 = rec[0], d1 = rec[1], d2 = rec[2], d3 = rec[3];
@@ -392,7 +439,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
 	// LJ-only sets (cheap bodies: the gathers are what has to be hidden): an iteration filters TWO trips (two candidates per lane)
 	// before it drains the queue — 128 listed pairs leave >= 64 inside the cutoff, so that (nearly) every iteration runs a body
 	// pass between the issue of the next iteration's gathers and their use.  The multipole body has no registers to spare for that.
-	constexpr int NC = LJ_ONLY ? 2 : 1;
 	uint32_t e2[NC], il2[NC];
 	Cand nxt[NC];
 #pragma unroll
@@ -509,7 +555,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
 	}
 	__syncthreads();
 	for (int k = lane; k < MSG; k += 64) {
-		const uint32_t p = p0 + (uint32_t)k;
+		const uint32_t p = msl_slot(P, p0 + (uint32_t)k);
 		if (p < n_real) {
 			P.Fx[p] = acc[0][k];
 			P.Fy[p] = acc[1][k];
@@ -536,11 +582,18 @@ uint32_t msl_groups(uint32_t n_real) { return (n_real + MSG - 1) / MSG; }
 
 int msl_capture_cap() { return MSL_CAP; }
 
+void launch_msl_groups(const ForceParams& p, uint32_t* gm, int ncomp, hipStream_t s) {
+	const uint32_t ng = msl_groups(p.n_real_cap);
+	if (ng == 0) return;
+	hipLaunchKernelGGL(k_msl_groups, dim3((ng * MSG + MSW - 1) / MSW), dim3(MSW), 0, s, p, gm, ncomp, ng * (uint32_t)MSG);
+}
+
 void launch_msl_count(const ForceParams& p, uint32_t* grp_cnt, uint32_t* off, uint32_t* scratch, uint16_t* mcnt, uint32_t stride,
 					  hipStream_t s) {
 	const uint32_t ng = msl_groups(p.n_real_cap);
 	if (ng == 0) return;
 	hipLaunchKernelGGL(k_msl_count, dim3(ng), dim3(MSG), 0, s, p, grp_cnt, scratch, mcnt, stride);
+	if (p.msl_gm) hipLaunchKernelGGL(k_msl_group_sums, dim3(ng), dim3(MSG), 0, s, p, grp_cnt, mcnt);
 	hipLaunchKernelGGL(k_msl_scan, dim3(1), dim3(1024), 0, s, grp_cnt, ng, off, p.cnt);
 }
 

@@ -141,6 +141,11 @@ struct ForcePass {
 	bool lists_rebuilt = false;  // list mode: the lists were rebuilt in this step (the displacement bound restarts)
 };
 
+static bool msl_lj_only(const ls1hip_ctx* c) {
+	bool lj_only = true;
+	for (int k = 0; k < c->h_ct.ncomp; ++k) lj_only = lj_only && c->h_ct.nc[k] == 0 && c->h_ct.nd[k] == 0 && c->h_ct.nq[k] == 0;
+	return lj_only;
+}
 static void fill_force_params(ls1hip_ctx* c, ForceParams& P, int which) {
 	memset(&P, 0, sizeof(P));
 	const MolSoA& m = c->mol[c->cur];
@@ -168,6 +173,7 @@ static void fill_force_params(ls1hip_ctx* c, ForceParams& P, int which) {
 	P.vl_ii = c->d_vl_ii;
 	P.vl_gi = c->d_vl_gi;
 	P.msl_gm = c->h_ct.ncomp > 1 ? c->d_msl_gm : nullptr;
+	P.msl_g = msl_group_size(msl_lj_only(c), c->h_ct.ncomp);
 }
 
 static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
@@ -215,8 +221,7 @@ static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
 	c->vl_top2_pending = local_post;
 	if (fp.vl && !c->one_clj) {
 		if (which != 0) FAIL(c, LS1HIP_EINVAL, "multi-site neighbour lists serve complete traversals (which = 0)");
-		bool lj_only = true;
-		for (int k = 0; k < c->h_ct.ncomp; ++k) lj_only = lj_only && c->h_ct.nc[k] == 0 && c->h_ct.nd[k] == 0 && c->h_ct.nq[k] == 0;
+		const bool lj_only = msl_lj_only(c);
 		// linear molecules (every LJ centre on the body z axis: ethane, the 2CLJ family): the axis form of the orientation
 		bool linear = lj_only;
 		for (int k = 0; k < c->h_ct.ncenters && linear; ++k) linear = c->h_ct.ljpos[k][0] == 0. && c->h_ct.ljpos[k][1] == 0.;
@@ -747,7 +752,7 @@ static int msl_build(ls1hip_ctx* c) {
 	int rc = ensure_rebuild_flag(c);
 	if (rc) return rc;
 	TimedScope ts(c, c->t_build);
-	const uint32_t ng = msl_groups((uint32_t)c->n_real);
+	const uint32_t ng = msl_groups((uint32_t)c->n_real, msl_group_size(msl_lj_only(c), c->h_ct.ncomp));
 	if ((size_t)ng + 1 > c->msl_groups_cap) {
 		dfree(c->d_msl_cnt);
 		dfree(c->d_msl_off);

@@ -108,6 +108,7 @@ struct ForceParams {
 	// multi-site pair-stream lists: molecule of every group slot (groups sorted by component inside windows of 8 groups), nullptr =
 	// slot s is molecule s (one component)
 	const uint32_t* msl_gm = nullptr;
+	int msl_g = 128;  // molecules per group (msl_group_size)
 	int count_pairs;
 	const uint32_t* brick_list;  // brick kernels: bricks of this pass (boundary), nullptr = all bricks / inner box
 	uint32_t n_list;
@@ -397,8 +398,8 @@ bool launch_force_ms(const ForceParams& p, bool with_vi, bool has_rot, bool one_
 bool launch_force_sites(const ForceParams& p, const CompTable& hct, bool with_vi, hipStream_t s, uint32_t* nblocks,
 						size_t partials_cap, double mean_per_cell, double mean_neighbours, BrickLists* bl);
 // multi-site neighbour lists (kernels_force_mslist.hip): count + offsets, fill, force pass over the pair stream
-int msl_group_size();
-uint32_t msl_groups(uint32_t n_real);
+int msl_group_size(bool lj_only, int ncomp);
+uint32_t msl_groups(uint32_t n_real, int g);
 int msl_capture_cap();  // hits per molecule the count kernel keeps for the fill kernel (scratch[k][stride])
 void launch_msl_groups(const ForceParams& p, uint32_t* gm, int ncomp, hipStream_t s);
 void launch_msl_count(const ForceParams& p, uint32_t* grp_cnt, uint32_t* off, uint32_t* scratch, uint16_t* mcnt, uint32_t stride,

@@ -54,12 +54,14 @@ __device__ __forceinline__ double msl_rsq(double d) {
 
 namespace ls1 {
 
-constexpr int MSG = 128;                    // molecules per group (= per wave of the force pass)
+// molecules per group (= per wave of the force pass): a template parameter MSG of the kernels below — 128, or 64 for one LJ-only
+// component (msl_group_size: cheap bodies, the occupancy is worth more than long runs)
+constexpr int MSG_MAX = 128;
 constexpr uint32_t MSL_IDX = 0x07ffffffu;  // pair entry: bits 0-26 molecule index, bits 27-31 shift index (13 = none)
 constexpr int MSL_MAXT = MAXC * MAXC;       // component pairs
-static_assert(MSG <= 128 && MAXC * MAXC <= 512, "queue entry: 7 bits local molecule, 9 bits component pair");
+static_assert(MSG_MAX <= 128 && MAXC * MAXC <= 512, "queue entry: 7 bits local molecule, 9 bits component pair");
 
-int msl_group_size() { return MSG; }
+int msl_group_size(bool lj_only, int ncomp) { return lj_only && ncomp == 1 ? 64 : MSG_MAX; }
 
 __device__ __forceinline__ uint32_t msl_wave_sum(uint32_t v) {
 	for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
@@ -196,6 +198,7 @@ __global__ void __launch_bounds__(MSW) k_msl_groups(ForceParams P, uint32_t* __r
 
 // ---- BUILD 1: pairs per group; the hits of every molecule are kept (first MSL_CAP of them) for the fill kernel ------------------
 constexpr int MSL_CAP = 32;  // captured hits per molecule: scratch[k][p], k < MSL_CAP (coalesced over p); more: the fill kernel walks again
+template <int MSG>
 __global__ void __launch_bounds__(MSG) k_msl_count(ForceParams P, uint32_t* grp_cnt, uint32_t* __restrict__ scratch,
 												   uint16_t* __restrict__ mcnt, uint32_t stride) {
 	__shared__ uint32_t wsum[MSG / 64];
@@ -214,8 +217,9 @@ __global__ void __launch_bounds__(MSG) k_msl_count(ForceParams P, uint32_t* grp_
 	cnt = msl_wave_sum(cnt);
 	if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
 	__syncthreads();
-	if (threadIdx.x == 0 && !P.msl_gm) grp_cnt[blockIdx.x] = wsum[0] + wsum[1];
+	if (threadIdx.x == 0 && !P.msl_gm) grp_cnt[blockIdx.x] = wsum[0] + (MSG > 64 ? wsum[MSG / 64 - 1] : 0u);
 }
+template <int MSG>
 __global__ void __launch_bounds__(MSG) k_msl_group_sums(ForceParams P, uint32_t* grp_cnt, const uint16_t* __restrict__ mcnt) {
 	__shared__ uint32_t wsum[MSG / 64];
 	const uint32_t n_real = P.n_fixed ? P.n_fixed : P.cnt->n_real;
@@ -223,7 +227,7 @@ __global__ void __launch_bounds__(MSG) k_msl_group_sums(ForceParams P, uint32_t*
 	uint32_t cnt = msl_wave_sum(p < n_real ? (uint32_t)mcnt[p] : 0u);
 	if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
 	__syncthreads();
-	if (threadIdx.x == 0) grp_cnt[blockIdx.x] = wsum[0] + wsum[1];
+	if (threadIdx.x == 0) grp_cnt[blockIdx.x] = wsum[0] + (MSG > 64 ? wsum[MSG / 64 - 1] : 0u);
 }
 
 // ---- BUILD 2: block offsets (each block padded to a multiple of 64 pairs); off[ngroups] = total -------------------------------
@@ -271,6 +275,7 @@ __device__ __forceinline__ void msl_hits(const ForceParams& P, uint32_t p, uint3
 	}
 }
 
+template <int MSG>
 __global__ void __launch_bounds__(MSG) k_msl_fill(ForceParams P, const uint32_t* __restrict__ off, const uint32_t* __restrict__ hsrc,
 												  const uint8_t* __restrict__ hdir, uint32_t* __restrict__ out_j,
 												  uint8_t* __restrict__ out_il, int ncomp, const uint32_t* __restrict__ scratch,
@@ -309,7 +314,7 @@ __global__ void __launch_bounds__(MSG) k_msl_fill(ForceParams P, const uint32_t*
 		__syncthreads();
 		const uint32_t pre = wv ? wsum[0] : 0u;
 		cur[t * MSG + tid] = run + pre + incl - mine;
-		run += wsum[0] + wsum[1];
+		run += wsum[0] + (MSG > 64 ? wsum[1] : 0u);
 		__syncthreads();
 	}
 	const uint32_t total = run, padded = (total + 63u) & ~63u, o0 = off[blockIdx.x];
@@ -346,9 +351,9 @@ __global__ void __launch_bounds__(256) k_msl_pack(ForceParams P, double* __restr
 // registers (four waves per SIMD instead of two: the gathers of a latency-bound pair stream want the occupancy)
 // LINEAR (with LJ_ONLY): every site of the set lies on the body z axis (ethane, the 2CLJ family): orientations are carried as the
 // rotated z axis (RotAxis, pairphys.hpp) — 24 VGPRs fewer than two rotation matrices (112 instead of 136), a third of the rotation
-// arithmetic.  (The occupancy stays at three waves per SIMD: 14 KB of LDS per wave; groups of 64 molecules would lift it to four
-// but were not built — MSG is baked into the list format.)
-template <bool WITH_ROT, bool LJ_ONLY, bool LINEAR = false>
+// arithmetic.
+// MSG = 64 (one LJ-only component): 8 KB of LDS per wave instead of 15 — the registers, not the LDS, then set the occupancy.
+template <bool WITH_ROT, bool LJ_ONLY, bool LINEAR = false, int MSG = MSG_MAX>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_force_ms_list(ForceParams P, const uint32_t* __restrict__ off, const uint32_t* __restrict__ pj,
 													  const uint8_t* __restrict__ pil, const double* __restrict__ shift27,
 													  const double* __restrict__ pk, const CompTable* __restrict__ ctab, uint32_t ngroups) {
@@ -578,46 +583,56 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
-uint32_t msl_groups(uint32_t n_real) { return (n_real + MSG - 1) / MSG; }
+uint32_t msl_groups(uint32_t n_real, int g) { return (n_real + (uint32_t)g - 1u) / (uint32_t)g; }
 
 int msl_capture_cap() { return MSL_CAP; }
 
 void launch_msl_groups(const ForceParams& p, uint32_t* gm, int ncomp, hipStream_t s) {
-	const uint32_t ng = msl_groups(p.n_real_cap);
+	const uint32_t ng = msl_groups(p.n_real_cap, p.msl_g);
 	if (ng == 0) return;
-	hipLaunchKernelGGL(k_msl_groups, dim3((ng * MSG + MSW - 1) / MSW), dim3(MSW), 0, s, p, gm, ncomp, ng * (uint32_t)MSG);
+	hipLaunchKernelGGL(k_msl_groups, dim3((ng * (uint32_t)p.msl_g + MSW - 1) / MSW), dim3(MSW), 0, s, p, gm, ncomp, ng * (uint32_t)p.msl_g);
 }
 
 void launch_msl_count(const ForceParams& p, uint32_t* grp_cnt, uint32_t* off, uint32_t* scratch, uint16_t* mcnt, uint32_t stride,
 					  hipStream_t s) {
-	const uint32_t ng = msl_groups(p.n_real_cap);
+	const uint32_t ng = msl_groups(p.n_real_cap, p.msl_g);
 	if (ng == 0) return;
-	hipLaunchKernelGGL(k_msl_count, dim3(ng), dim3(MSG), 0, s, p, grp_cnt, scratch, mcnt, stride);
-	if (p.msl_gm) hipLaunchKernelGGL(k_msl_group_sums, dim3(ng), dim3(MSG), 0, s, p, grp_cnt, mcnt);
+	if (p.msl_g == 64) hipLaunchKernelGGL(k_msl_count<64>, dim3(ng), dim3(64), 0, s, p, grp_cnt, scratch, mcnt, stride);
+	else hipLaunchKernelGGL(k_msl_count<128>, dim3(ng), dim3(128), 0, s, p, grp_cnt, scratch, mcnt, stride);
+	if (p.msl_gm && p.msl_g == 64) hipLaunchKernelGGL(k_msl_group_sums<64>, dim3(ng), dim3(64), 0, s, p, grp_cnt, mcnt);
+	else if (p.msl_gm) hipLaunchKernelGGL(k_msl_group_sums<128>, dim3(ng), dim3(128), 0, s, p, grp_cnt, mcnt);
 	hipLaunchKernelGGL(k_msl_scan, dim3(1), dim3(1024), 0, s, grp_cnt, ng, off, p.cnt);
 }
 
 void launch_msl_fill(const ForceParams& p, const uint32_t* off, const uint32_t* hsrc, const uint8_t* hdir, uint32_t* out_j,
 					 uint8_t* out_il, int ncomp, const uint32_t* scratch, const uint16_t* mcnt, uint32_t stride, hipStream_t s) {
-	const uint32_t ng = msl_groups(p.n_real_cap);
+	const uint32_t ng = msl_groups(p.n_real_cap, p.msl_g);
 	if (ng == 0) return;
-	hipLaunchKernelGGL(k_msl_fill, dim3(ng), dim3(MSG), 0, s, p, off, hsrc, hdir, out_j, out_il, ncomp, scratch, mcnt, stride);
+	if (p.msl_g == 64) hipLaunchKernelGGL(k_msl_fill<64>, dim3(ng), dim3(64), 0, s, p, off, hsrc, hdir, out_j, out_il, ncomp, scratch, mcnt, stride);
+	else hipLaunchKernelGGL(k_msl_fill<128>, dim3(ng), dim3(128), 0, s, p, off, hsrc, hdir, out_j, out_il, ncomp, scratch, mcnt, stride);
 }
 
 bool launch_force_ms_list(const ForceParams& p, bool has_rot, bool lj_only, bool linear, int ncomp, const uint32_t* off, const uint32_t* pj, const uint8_t* pil,
 						  const double* shift27, double* pk, hipStream_t s, uint32_t* nblocks, size_t partials_cap, bool pk_fresh) {
-	const uint32_t ng = msl_groups(p.n_real_cap);
+	const uint32_t ng = msl_groups(p.n_real_cap, p.msl_g);
 	if ((size_t)ng > partials_cap || p.which != 0) return false;
 	*nblocks = ng;
 	if (ng == 0) return true;
 	const uint32_t grid = ((ng + 7u) >> 3) << 3;  // (8 chunks of consecutive groups, see the kernel)
 	// (pk_fresh: the last rigid-body kick + drift pass wrote the records of the current state itself)
 	if (!pk_fresh) hipLaunchKernelGGL(k_msl_pack, dim3((p.n_real_cap + 255u) / 256u), dim3(256), 0, s, p, pk, has_rot ? 1 : 0, ncomp);
-	if (has_rot && lj_only && linear) hipLaunchKernelGGL((k_force_ms_list<true, true, true>), dim3(grid), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct, ng);
-	else if (has_rot && lj_only) hipLaunchKernelGGL((k_force_ms_list<true, true>), dim3(grid), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct, ng);
-	else if (has_rot) hipLaunchKernelGGL((k_force_ms_list<true, false>), dim3(grid), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct, ng);
-	else if (lj_only) hipLaunchKernelGGL((k_force_ms_list<false, true>), dim3(grid), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct, ng);
-	else hipLaunchKernelGGL((k_force_ms_list<false, false>), dim3(grid), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct, ng);
+#define LS1_MSL_LAUNCH(...) hipLaunchKernelGGL((k_force_ms_list<__VA_ARGS__>), dim3(grid), dim3(64), 0, s, p, off, pj, pil, shift27, pk, p.ct, ng)
+	if (p.msl_g == 64) {  // (one LJ-only component, msl_group_size)
+		if (!lj_only) return false;
+		if (has_rot && linear) LS1_MSL_LAUNCH(true, true, true, 64);
+		else if (has_rot) LS1_MSL_LAUNCH(true, true, false, 64);
+		else LS1_MSL_LAUNCH(false, true, false, 64);
+	} else if (has_rot && lj_only && linear) LS1_MSL_LAUNCH(true, true, true);
+	else if (has_rot && lj_only) LS1_MSL_LAUNCH(true, true);
+	else if (has_rot) LS1_MSL_LAUNCH(true, false);
+	else if (lj_only) LS1_MSL_LAUNCH(false, true);
+	else LS1_MSL_LAUNCH(false, false);
+#undef LS1_MSL_LAUNCH
 	return true;
 }
 

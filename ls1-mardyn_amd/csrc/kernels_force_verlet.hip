@@ -61,6 +61,7 @@
 #define LS1_HOOK_RECORD_OF(did) (did)
 #define LS1_HOOK_OWN_FROM_LDS true
 #define LS1_HOOK_DMA_STAGING true
+#define LS1_HOOK_STAGGER() ((void)0)
 #endif
 
 namespace ls1 {
@@ -972,6 +973,7 @@ __global__ void __launch_bounds__(VNT, 4) k_force_lj_verlet(ForceParams P, int n
 		if (tid < 4) P.partials[(size_t)blockIdx.x * 4 + tid] = 0.;
 		return;
 	}
+	LS1_HOOK_STAGGER();  // (nothing; timing variants)
 	ListHead head;
 	Totals tot = {0., 0., 0., 0., 0.};
 	uint32_t* const rec = P.vl_rec + (size_t)did * VREC;

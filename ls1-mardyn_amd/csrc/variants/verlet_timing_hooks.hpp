@@ -70,3 +70,17 @@
 #else
 #define LS1_HOOK_DMA_STAGING true
 #endif
+
+//   -DLS1_X_STAGGER      the workgroups of the FIRST round (the first 512: two per CU) start with a pseudo-random delay of 0-24 us (one
+//                        workgroup lifetime): do the two workgroups of a CU run their memory and pair-loop phases in lockstep?  (correct results)
+#if defined(LS1_X_STAGGER)
+#define LS1_HOOK_STAGGER()                                                                    \
+	do {                                                                                      \
+		if (blockIdx.x < 512u) {                                                              \
+			const uint32_t h_ = (blockIdx.x * 2654435761u) >> 29;                             \
+			for (uint32_t i_ = 0; i_ < h_; ++i_) __builtin_amdgcn_s_sleep(127);               \
+		}                                                                                     \
+	} while (0)
+#else
+#define LS1_HOOK_STAGGER() ((void)0)
+#endif

@@ -490,7 +490,7 @@ def main():
         if args.gpus != 1 or args.decomp:
             sys.exit("bench.py --workload ethane|mixed runs on one GPU (multi-site lists serve single-rank domains)")
         if args.skin == 0.2:  # the default is in sigma of the LJ liquid; multi-site boxes are in atomic units
-            args.skin = {"ethane": 4.0, "mixed": 3.0}[args.workload]  # (sweep: profiles/r3_ms_skin_sweep.txt)
+            args.skin = {"ethane": 6.0, "mixed": 5.0}[args.workload]  # (sweep: profiles/r4_ms_skin_sweep.txt — the cutoff filter of the force pass makes skin pairs cheap)
 
     # stdout carries ONE JSON line: libraries that print to file descriptor 1 (RCCL prints a version banner when the first
     # communicator is created) are sent to stderr for the duration of the run; the result goes to the saved descriptor

@@ -81,6 +81,14 @@ bool can_fuse(const ls1hip_ctx* c) {
 		   (c->g.hw == 1 || c->g.hw == 2);
 }
 
+// rigid bodies of ONE component under pair-stream lists: the list pass integrates its own molecules (kernels_force_mslist.hip,
+// leapfrog_body.hpp).  Several components: measured, no gain — the groups go through the slot map there, the epilogue's 8-byte
+// accesses are scattered over a window of 1024 molecules and cost what the separate (coalesced) integrator pass costs.
+bool can_fuse_ms(const ls1hip_ctx* c) {
+	return c->have_comp && !c->one_clj && c->h_ct.has_rot && c->h_ct.ncomp == 1 && c->opt_force_kernel != LS1HIP_FK_GENERIC && !c->opt_vi &&
+		   !c->opt_count_pairs && !c->thermostat_on && !c->has_remote;
+}
+
 extern "C" int ls1hip_set_option(ls1hip_ctx* c, const char* name, long v) {
 	if (!c || !name) return LS1HIP_EINVAL;
 	std::string n(name);

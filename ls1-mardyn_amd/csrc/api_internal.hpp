@@ -111,7 +111,7 @@ static inline void free_mol(ls1hip_ctx* c) {
 	dfree(c->alt_x); dfree(c->alt_y); dfree(c->alt_z);
 	dfree(c->d_vl_words); dfree(c->d_vl_nw); dfree(c->d_vl_rec); dfree(c->d_vl_ii); dfree(c->d_vl_gi);
 	dfree(c->d_vl_top2); dfree(c->d_vl_acc);
-	dfree(c->d_msl_cnt); dfree(c->d_msl_off); dfree(c->d_msl_j); dfree(c->d_msl_il); dfree(c->d_msl_scratch); dfree(c->d_msl_mcnt); dfree(c->d_msl_pk); dfree(c->d_msl_gm);
+	dfree(c->d_msl_cnt); dfree(c->d_msl_off); dfree(c->d_msl_j); dfree(c->d_msl_il); dfree(c->d_msl_scratch); dfree(c->d_msl_mcnt); dfree(c->d_msl_pk); dfree(c->d_msl_pk2); dfree(c->d_msl_gm);
 	c->msl_groups_cap = c->msl_pairs_cap = c->msl_stride = 0;
 	dfree(c->seam_a_buf);
 	c->seam_a_cap = 0;
@@ -132,6 +132,7 @@ static inline void free_cells(ls1hip_ctx* c) {
 
 // ---- helpers defined in one translation unit and used by another ---------------------------------------------------------------
 LS1_INTERNAL bool can_fuse(const ls1hip_ctx* c);
+LS1_INTERNAL bool can_fuse_ms(const ls1hip_ctx* c);
 LS1_INTERNAL hipStream_t halo_stream(ls1hip_ctx* c);
 LS1_INTERNAL int sync_counters(ls1hip_ctx* c, hipStream_t s = nullptr);
 LS1_INTERNAL int d2h3(ls1hip_ctx* c, size_t n, const double* a, const double* b, const double* d, double* out, int stride, int o);

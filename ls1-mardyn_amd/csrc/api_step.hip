@@ -194,7 +194,7 @@ static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
 		if (c->pos_x) {  // current positions (owned + refreshed halo) live in the second buffer
 			P.x = c->pos_x; P.y = c->pos_y; P.z = c->pos_z;
 		}
-		if (fuse) {  // the advanced positions go to the other buffer
+		if (fuse && c->one_clj) {  // the advanced positions go to the other buffer
 			const bool in_alt = c->pos_x == c->alt_x;
 			P.Fx = in_alt ? m.x : c->alt_x;
 			P.Fy = in_alt ? m.y : c->alt_y;
@@ -225,9 +225,20 @@ static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
 		// linear molecules (every LJ centre on the body z axis: ethane, the 2CLJ family): the axis form of the orientation
 		bool linear = lj_only;
 		for (int k = 0; k < c->h_ct.ncenters && linear; ++k) linear = c->h_ct.ljpos[k][0] == 0. && c->h_ct.ljpos[k][1] == 0.;
+		if (fuse) {  // the pass integrates its molecules itself: state in place, next step's records to the other record buffer
+			const MolSoA& ms = c->mol[c->cur];
+			P.Dx = ms.Dx; P.Dy = ms.Dy; P.Dz = ms.Dz;
+			P.msl_pk_out = c->d_msl_pk2;
+			P.msl_vmax = c->d_partials + (size_t)4 * msl_groups((uint32_t)c->n_real, P.msl_g);  // behind the macroscopic partials
+		}
 		done = launch_force_ms_list(P, c->h_ct.has_rot != 0, lj_only, linear, c->h_ct.ncomp, c->d_msl_off, c->d_msl_j, c->d_msl_il, c->d_shift27, c->d_msl_pk,
 									c->stream, &nblocks, c->partials_cap, c->msl_pk_fresh);
 		if (!done) FAIL(c, LS1HIP_EINVAL, "multi-site neighbour-list force pass could not be launched");
+		if (fuse) {
+			// the displacement bound of the lists, from the drift speeds the epilogue left per group (as track_unfused_drift)
+			launch_bound_update(c->d_cnt, P.msl_vmax, nblocks, fp.dt, 0.5 * c->vl_skin, c->vl_fresh, ++c->vl_seq, c->d_flag, c->stream, false);
+			std::swap(c->d_msl_pk, c->d_msl_pk2);
+		}
 		family = LS1HIP_FK_NEIGHBOUR_LIST;
 	} else if (fp.vl) {
 		done = launch_force_verlet(P, c->stream, &nblocks, c->partials_cap, &c->brick_lists);
@@ -265,10 +276,10 @@ static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
 	}
 	ReduceMode rm;
 	rm.overwrite = first_pass && !c->opt_count_pairs;
-	rm.kin_in_slot1 = fuse || fp.post_kick;
+	rm.kin_in_slot1 = (fuse && c->one_clj) || fp.post_kick;
 	rm.target_T = (fp.post_kick && c->thermostat_on) ? c->thermostat_T : 0.;
 	rm.log = c->log_row;
-	if (fp.vl && fuse) {
+	if (fp.vl && fuse && c->one_clj) {
 		rm.vmax_in_slot2 = true;
 		rm.last_pass = which != 1;
 		rm.lists_rebuilt = fp.lists_rebuilt;
@@ -767,10 +778,11 @@ static int msl_build(ls1hip_ctx* c) {
 		dfree(c->d_msl_scratch);
 		dfree(c->d_msl_mcnt);
 		dfree(c->d_msl_pk);
+		dfree(c->d_msl_pk2);
 		c->msl_stride = 0;
 		const size_t stride = (c->cap_real + 63) & ~(size_t)63;
 		if ((rc = dalloc(c, &c->d_msl_scratch, stride * (size_t)msl_capture_cap())) || (rc = dalloc(c, &c->d_msl_mcnt, stride)) ||
-			(rc = dalloc(c, &c->d_msl_pk, stride * 8)))
+			(rc = dalloc(c, &c->d_msl_pk, stride * 8)) || (rc = dalloc(c, &c->d_msl_pk2, stride * 8)))
 			return rc;
 		c->msl_stride = stride;
 	}
@@ -862,7 +874,8 @@ static int forces_list_impl(ls1hip_ctx* c, int which, double dt, bool post_kick,
 	REQUIRE(c, dt >= 0., "dt must be >= 0 (0: forces only, > 0: fused with kick + kick + drift)");
 	const bool fuse = dt > 0. && !post_kick;
 	REQUIRE(c, !post_kick || which == 0, "the post-force kick is folded into complete traversals only");
-	REQUIRE(c, !fuse || can_fuse(c), "fused list passes: no per-molecule virial, no device thermostat");
+	REQUIRE(c, !fuse || (c->one_clj ? can_fuse(c) : (can_fuse_ms(c) && which == 0)),
+			"fused list passes: single-centre LJ or rigid multi-site bodies (complete traversals), no per-molecule virial, no device thermostat");
 	REQUIRE(c, (fuse && which == 2) ? c->fused_split == 1 : c->fused_split == 0,
 			"fused list passes must be which=0, or which=1 followed by which=2");
 	HIPCHK(c, hipSetDevice(c->device));
@@ -883,17 +896,20 @@ static int forces_list_impl(ls1hip_ctx* c, int which, double dt, bool post_kick,
 		c->inner_in_flight = !c->halo_valid;
 		if (fuse) c->fused_split = 1;
 	} else if (fuse) {
-		// velocities are at t + dt/2 of the next step; the advanced positions wait in the other position buffer
-		const bool in_alt = c->pos_x == c->alt_x;
-		c->pos_x = in_alt ? nullptr : c->alt_x;
-		c->pos_y = in_alt ? nullptr : c->alt_y;
-		c->pos_z = in_alt ? nullptr : c->alt_z;
+		// velocities are at t + dt/2 of the next step; the advanced positions wait in the other position buffer (single-centre
+		// LJ), or are in place with the next step's records in the record buffer (rigid bodies: launch_forces swapped the two)
+		if (c->one_clj) {
+			const bool in_alt = c->pos_x == c->alt_x;
+			c->pos_x = in_alt ? nullptr : c->alt_x;
+			c->pos_y = in_alt ? nullptr : c->alt_y;
+			c->pos_z = in_alt ? nullptr : c->alt_z;
+		}
 		c->fused_split = 0;
 		c->vl_fresh = false;
 		c->vl_bound_pending = true;
 		c->halo_valid = false;
 		c->forces_valid = false;
-		c->msl_pk_fresh = false;
+		c->msl_pk_fresh = !c->one_clj;
 		c->vl_steps++;
 	} else {
 		c->forces_valid = true;
@@ -945,7 +961,7 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 	HIPCHK(c, hipSetDevice(c->device));
 	// Between two steps of an NVE run on the LJ fast path the force pass does the integration itself (fused mode, the
 	// reference's reduced-memory scheme); the last step is unfused so that F and the kinetic sums are available.
-	const bool fuse = c->opt_fuse && can_fuse(c);
+	const bool fuse = c->opt_fuse && (can_fuse(c) || (can_verlet(c) && can_list_ms(c) && can_fuse_ms(c)));
 	// neighbour-list loop (fused or not: NVT and unfused NVE steps advance the displacement bound in their kick + drift pass)
 	const bool verlet = can_verlet(c) && can_list(c);
 	// the single-centre list pass does the post-force kick (+ sum m v^2) itself; the multi-site one leaves it to the integrator passes

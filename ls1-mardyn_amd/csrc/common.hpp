@@ -109,6 +109,11 @@ struct ForceParams {
 	// slot s is molecule s (one component)
 	const uint32_t* msl_gm = nullptr;
 	int msl_g = 128;  // molecules per group (msl_group_size)
+	// fused pair-stream pass of rigid bodies (fuse = 1): the epilogue integrates the group's molecules (leapfrog_body.hpp) — x y z,
+	// q, v (vx..), D in place, next step's records to msl_pk_out (the pass reads the other record buffer), max |v|^2 per group
+	double *Dx = nullptr, *Dy = nullptr, *Dz = nullptr;
+	double* msl_pk_out = nullptr;
+	double* msl_vmax = nullptr;
 	int count_pairs;
 	const uint32_t* brick_list;  // brick kernels: bricks of this pass (boundary), nullptr = all bricks / inner box
 	uint32_t n_list;
@@ -264,6 +269,7 @@ struct ls1hip_ctx {
 	uint32_t* d_msl_scratch = nullptr;  // [msl_capture_cap()][msl_stride]: hits captured by the count kernel
 	uint16_t* d_msl_mcnt = nullptr;     // [msl_stride]: hits per molecule
 	uint32_t* d_msl_gm = nullptr;       // [groups * 128]: molecule of every group slot (k_msl_groups; several components only)
+	double* d_msl_pk2 = nullptr;        // the record buffer a fused pass writes (the two trade places after it)
 	double* d_msl_pk = nullptr;         // [msl_stride][8]: packed per-step state of the owned molecules (k_msl_pack)
 	bool msl_pk_fresh = false;          // ... and it holds the CURRENT positions / orientations (written by the last kick + drift pass)
 	size_t msl_stride = 0;

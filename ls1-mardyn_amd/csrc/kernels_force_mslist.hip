@@ -51,6 +51,7 @@ __device__ __forceinline__ double msl_rsq(double d) {
 #include <type_traits>
 
 #include "common.hpp"
+#include "leapfrog_body.hpp"
 
 namespace ls1 {
 
@@ -559,6 +560,37 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
 		if (!more) break;
 	}
 	__syncthreads();
+	bool integrated = false;
+	if constexpr (WITH_ROT) if (P.fuse == 1) {
+		// FUSED: upd_postF of this step and upd_preF of the next for the group's molecules, straight from the accumulators — the
+		// forces never go to memory, v and D are read and written once, and the records of the next step are written here (into
+		// the OTHER record buffer: this launch still reads the current one).  Same arithmetic as k_kick_then_kick_drift.
+		double v2max = 0.;
+		for (int k = lane; k < MSG; k += 64) {
+			const uint32_t p = msl_slot(P, p0 + (uint32_t)k);
+			if (p < n_real) {
+				const int c = sci[k];
+				LeapState st;
+				st.x = sr[0][k]; st.y = sr[1][k]; st.z = sr[2][k];  // (the record's position IS the state's)
+				st.vx = P.vx[p]; st.vy = P.vy[p]; st.vz = P.vz[p];
+				st.q[0] = P.q0[p]; st.q[1] = P.q1[p]; st.q[2] = P.q2[p]; st.q[3] = P.q3[p];  // (the record's is normalised once more)
+				st.D = {P.Dx[p], P.Dy[p], P.Dz[p]};
+				const V3 F = {acc[0][k], acc[1][k], acc[2][k]}, M = {acc[3][k], acc[4][k], acc[5][k]};
+				const V3 invI = {ct.invI[c][0], ct.invI[c][1], ct.invI[c][2]};
+				v2max = fmax(v2max, leap_post_pre<true>(P.dt, ct.mass[c], invI, F, M, st));
+				const_cast<double*>(P.x)[p] = st.x; const_cast<double*>(P.y)[p] = st.y; const_cast<double*>(P.z)[p] = st.z;
+				P.vx[p] = st.vx; P.vy[p] = st.vy; P.vz[p] = st.vz;
+				const_cast<double*>(P.q0)[p] = st.q[0]; const_cast<double*>(P.q1)[p] = st.q[1];
+				const_cast<double*>(P.q2)[p] = st.q[2]; const_cast<double*>(P.q3)[p] = st.q[3];
+				P.Dx[p] = st.D.x; P.Dy[p] = st.D.y; P.Dz[p] = st.D.z;
+				msl_write_record(P.msl_pk_out, p, st.x, st.y, st.z, st.q[0], st.q[1], st.q[2], st.q[3], true, c);
+			}
+		}
+		for (int o = 32; o > 0; o >>= 1) v2max = fmax(v2max, __shfl_down(v2max, o));
+		if (lane == 0) P.msl_vmax[grp] = v2max;
+		integrated = true;
+	}
+	if (!integrated)
 	for (int k = lane; k < MSG; k += 64) {
 		const uint32_t p = msl_slot(P, p0 + (uint32_t)k);
 		if (p < n_real) {

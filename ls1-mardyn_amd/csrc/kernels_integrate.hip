@@ -4,6 +4,7 @@
 // Restates FullMolecule::upd_preF (/root/reference/src/molecules/FullMolecule.cpp:334-364) and upd_postF (:366-389)
 // as driven by Leapfrog::transition1to2 / transition2to3 (/root/reference/src/integrators/Leapfrog.cpp:48-64,66-150).
 #include "common.hpp"
+#include "leapfrog_body.hpp"
 
 namespace ls1 {
 
@@ -104,54 +105,27 @@ __global__ void __launch_bounds__(ITPB) k_kick_then_kick_drift(IntegArgs a) {
 	const uint32_t p = blockIdx.x * ITPB + threadIdx.x;
 	double v2 = 0.;
 	if (p < a.cnt->n_real) {
-	const double dt = a.dt, dt_halve = .5 * dt;
 	const int c = HAS_ROT ? a.mol.cid[p] : (a.ct->ncomp > 1 ? a.mol.cid[p] : 0);
-	const double dtInv2m = dt_halve / a.ct->mass[c];
-	const double Fx = a.frc.Fx[p], Fy = a.frc.Fy[p], Fz = a.frc.Fz[p];
-	double vx = a.mol.vx[p] + dtInv2m * Fx;  // upd_postF
-	double vy = a.mol.vy[p] + dtInv2m * Fy;
-	double vz = a.mol.vz[p] + dtInv2m * Fz;
-	vx += dtInv2m * Fx;  // upd_preF
-	vy += dtInv2m * Fy;
-	vz += dtInv2m * Fz;
-	a.mol.vx[p] = vx;
-	a.mol.vy[p] = vy;
-	a.mol.vz[p] = vz;
-	v2 = vx * vx + vy * vy + vz * vz;
-	const double xn = a.mol.x[p] + dt * vx, yn = a.mol.y[p] + dt * vy, zn = a.mol.z[p] + dt * vz;
-	a.mol.x[p] = xn;
-	a.mol.y[p] = yn;
-	a.mol.z[p] = zn;
+	// (the arithmetic: leapfrog_body.hpp, shared with the fused epilogue of the pair-stream force pass)
+	LeapState s;
+	s.x = a.mol.x[p]; s.y = a.mol.y[p]; s.z = a.mol.z[p];
+	s.vx = a.mol.vx[p]; s.vy = a.mol.vy[p]; s.vz = a.mol.vz[p];
+	const V3 F = {a.frc.Fx[p], a.frc.Fy[p], a.frc.Fz[p]};
+	V3 M = {0., 0., 0.}, invI = {0., 0., 0.};
 	if (HAS_ROT) {
-		double q[4] = {a.mol.q0[p], a.mol.q1[p], a.mol.q2[p], a.mol.q3[p]};
-		const double Mx = a.frc.Mx[p], My = a.frc.My[p], Mz = a.frc.Mz[p];
-		V3 D = {a.mol.Dx[p] + dt_halve * Mx, a.mol.Dy[p] + dt_halve * My, a.mol.Dz[p] + dt_halve * Mz};  // upd_postF
-		const V3 invI = {a.ct->invI[c][0], a.ct->invI[c][1], a.ct->invI[c][2]};
-		V3 w = rotate_inv(rot_of(q[0], q[1], q[2], q[3]), D);
-		w = {w.x * invI.x, w.y * invI.y, w.z * invI.z};
-		double dq[4], qh[4];
-		q_diff(q, w, dq);
-		for (int k = 0; k < 4; ++k) qh[k] = dq[k] * dt_halve + q[k];
-		double qcorr = 1. / sqrt(qh[0] * qh[0] + qh[1] * qh[1] + qh[2] * qh[2] + qh[3] * qh[3]);
-		for (int k = 0; k < 4; ++k) qh[k] *= qcorr;
-		D.x += dt_halve * Mx;
-		D.y += dt_halve * My;
-		D.z += dt_halve * Mz;
-		w = rotate_inv(rot_of(qh[0], qh[1], qh[2], qh[3]), D);
-		w = {w.x * invI.x, w.y * invI.y, w.z * invI.z};
-		q_diff(qh, w, dq);
-		for (int k = 0; k < 4; ++k) q[k] += dq[k] * dt;
-		qcorr = 1. / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-		const double qs0 = q[0] * qcorr, qs1 = q[1] * qcorr, qs2 = q[2] * qcorr, qs3 = q[3] * qcorr;
-		a.mol.q0[p] = qs0;
-		a.mol.q1[p] = qs1;
-		a.mol.q2[p] = qs2;
-		a.mol.q3[p] = qs3;
-		a.mol.Dx[p] = D.x;
-		a.mol.Dy[p] = D.y;
-		a.mol.Dz[p] = D.z;
+		s.q[0] = a.mol.q0[p]; s.q[1] = a.mol.q1[p]; s.q[2] = a.mol.q2[p]; s.q[3] = a.mol.q3[p];
+		s.D = {a.mol.Dx[p], a.mol.Dy[p], a.mol.Dz[p]};
+		M = {a.frc.Mx[p], a.frc.My[p], a.frc.Mz[p]};
+		invI = {a.ct->invI[c][0], a.ct->invI[c][1], a.ct->invI[c][2]};
+	}
+	v2 = leap_post_pre<HAS_ROT>(a.dt, a.ct->mass[c], invI, F, M, s);
+	a.mol.vx[p] = s.vx; a.mol.vy[p] = s.vy; a.mol.vz[p] = s.vz;
+	a.mol.x[p] = s.x; a.mol.y[p] = s.y; a.mol.z[p] = s.z;
+	if (HAS_ROT) {
+		a.mol.q0[p] = s.q[0]; a.mol.q1[p] = s.q[1]; a.mol.q2[p] = s.q[2]; a.mol.q3[p] = s.q[3];
+		a.mol.Dx[p] = s.D.x; a.mol.Dy[p] = s.D.y; a.mol.Dz[p] = s.D.z;
 		// the record of the pair-stream force pass, from the values just stored (what k_msl_pack would read back)
-		if (a.pk) msl_write_record(a.pk, p, xn, yn, zn, qs0, qs1, qs2, qs3, true, a.pk_ncomp > 1 ? c : 0);
+		if (a.pk) msl_write_record(a.pk, p, s.x, s.y, s.z, s.q[0], s.q[1], s.q[2], s.q[3], true, a.pk_ncomp > 1 ? c : 0);
 	}
 	}
 	if (a.vmax_part) block_vmax(v2, a.vmax_part);

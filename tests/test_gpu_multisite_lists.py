@@ -204,6 +204,40 @@ def test_multisite_list_loop_equals_per_step_kernels_over_many_rebuilds(which):
     assert np.allclose(a[2][:, :4], b[2][:, :4], rtol=1e-10, atol=0, equal_nan=True)  # (NaN = not computed in that step, in both loops)
 
 
+@pytest.mark.parametrize("which", ["ethane", "polar"])
+def test_fused_rigid_body_list_pass_equals_the_separate_integrator_bitwise(which):
+    """ls1hip_run over several list lifetimes with the list pass integrating its own molecules (fuse_integration = 1: the
+    epilogue of k_force_ms_list, leapfrog_body.hpp) and with the separate kick + kick + drift pass (0): the same bits — a run
+    may switch between the two at any step (the last step of a run is always unfused)."""
+    comps, length, rc, ids, cid, r, v, q, D = _mixture_in_the_ethane_box()
+    # one component each (the fused pass serves single-component rigid sets): the LJ-only linear instantiation with groups of 64,
+    # and the general one (two LJ centres + a dipole: torques from the multipole bodies, groups of 128)
+    comps = inp.ComponentSet([comps.components[0 if which == "ethane" else 2]], np.zeros((0, 2)), 1e10)
+    cid = np.zeros_like(cid)
+    v = v * 3.0
+    res = {}
+    for fuse in (1, 0):
+        e = engine_mod.DeviceEngine(0)
+        e.set_components(comps, rc)
+        e.set_verlet(4.0)
+        e.set_domain(length)
+        e.set_option("fuse_integration", fuse)
+        e.upload(ids, cid, r, v, q, D)
+        e.rebin(); e.halo(); e.forces(0)
+        out = e.run(0.5, 17)
+        out2 = e.run(0.5, 13)  # (a second run: starts from the unfused last step of the first)
+        assert e.get_option("last_force_kernel") == capi.FK_NEIGHBOUR_LIST
+        assert e.get_option("verlet_builds") >= 3
+        res[fuse] = (_sorted(e), out, out2)
+        e.close()
+    a, b = res[1], res[0]
+    for k in ("r", "v", "q", "D", "F", "M"):
+        assert np.array_equal(a[0][k], b[0][k]), k
+    for o in (1, 2):
+        for k in ("upot", "virial", "summv2", "sumIw2"):
+            assert a[o][k] == b[o][k], k
+
+
 def test_config3_ethane_10m_replicated_through_the_list_pass():
     """configs[3] at full size (the reference's ethane box replicated 10^3 = 9 826 000 molecules) through the list build and
     the list force pass: every replica reproduces the golden forces / torques of the real reference, U_pot and virial are

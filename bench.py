@@ -39,6 +39,9 @@ FUSED_BYTES_PER_MOLECULE = 96.0
 PMC_SUMMARY = "r2_pmc_summary.json"  # rocprofv3 PMC passes of this workload (tools/collect_profiles.sh)
 STEP_BYTES_PER_MOLECULE = 292.0   # full step: force 48 + integrator 120 + re-bin 124
 MS_FORCE_BYTES_PER_MOLECULE = 104.0  # multi-site force pass: read r 24 + q 32, write F 24 + M 24
+# fused rigid-body list pass (single-component sets, between steps): read r q v D (104 B) + write r q v D (104 B); F and M never
+# reach HBM and the 256 B integrator pass disappears
+MS_FUSED_BYTES_PER_MOLECULE = 208.0
 HBM_PEAK_GBS = 8000.0
 BASELINE_METRIC = "particle-updates/sec (whole node), 10^8 LJ liquid Argon, rc=2.5\u03c3"  # BASELINE.json, verbatim
 
@@ -726,9 +729,11 @@ def main():
         step_bytes_total = n_local * ((FUSED_BYTES_PER_MOLECULE + 124.0) * n_fused + STEP_BYTES_PER_MOLECULE * (args.steps - n_fused))
     else:
         # multi-site force pass (48 B + 56 B for the orientation in and the torque out): read r 24 + q 32, write F 24 + M 24
-        alg_bytes_total = n_local * MS_FORCE_BYTES_PER_MOLECULE * args.steps
-        # + rigid-body integrator pass: read r v q D F M (152 B), write r v q D (104 B)
-        step_bytes_total = n_local * (MS_FORCE_BYTES_PER_MOLECULE + 256.0) * args.steps
+        fused_on = bool(e.get_option("fuse_integration")) and bool(e.get_option("can_fuse_rigid_lists")) and e.get_option("verlet_builds") > 0
+        n_fused = (args.steps - 1) if fused_on else 0
+        alg_bytes_total = n_local * (MS_FUSED_BYTES_PER_MOLECULE * n_fused + MS_FORCE_BYTES_PER_MOLECULE * (args.steps - n_fused))
+        # unfused: + rigid-body integrator pass: read r v q D F M (152 B), write r v q D (104 B)
+        step_bytes_total = n_local * (MS_FUSED_BYTES_PER_MOLECULE * n_fused + (MS_FORCE_BYTES_PER_MOLECULE + 256.0) * (args.steps - n_fused))
     alg_bytes_per_launch = alg_bytes_total / max(force_n, 1)
     traffic = None
     pmc_extra = {}

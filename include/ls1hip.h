@@ -88,7 +88,9 @@ const char* ls1hip_version(void);
  *   cells first, the halo built on a second stream meanwhile, then the boundary cells — the order a transport-driven
  *   multi-rank loop uses; 2 = halo, inner cells, boundary cells on one stream),
  * "fuse_integration" (0|1, default 1: ls1hip_run lets the force pass do the integration between steps, see
- * ls1hip_forces_kick_drift), "can_fuse_integration" (read only),
+ * ls1hip_forces_kick_drift), "can_fuse_integration" (read only), "can_fuse_rigid_lists" (read only: a single-component
+ *   rigid multi-site set under neighbour lists — ls1hip_run lets the pair-stream list pass integrate its own molecules,
+ *   ls1hip_forces_list with dt > 0 does it piecewise; bitwise the separate kick + kick + drift pass),
  * "lj_split" (variant of the single-centre LJ fast path; results are the same to rounding, only speed differs:
  *   0 = choose from the mean cell occupancy (default); 1 | 2 = list kernel with 1 | 2 lanes per molecule;
  *   4 = FP32 MFMA distance-tile pre-filter + exact FP64 evaluation, 1x4x4-cell bricks, 512 threads;

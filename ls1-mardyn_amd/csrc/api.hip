@@ -170,6 +170,7 @@ extern "C" int ls1hip_get_option(const ls1hip_ctx* c, const char* name, long* v)
 		}
 	} else if (n == "precision_in_use") *v = (c->opt_precision && c->vl_ready && c->vl_all_regular) ? c->opt_precision : 0;
 	else if (n == "can_fuse_integration") *v = can_fuse(c) ? 1 : 0;
+	else if (n == "can_fuse_rigid_lists") *v = (c->vl_on && can_fuse_ms(c)) ? 1 : 0;
 	else if (n == "list_kick_available") *v = (c->vl_ready && c->one_clj) ? 1 : 0;
 	else if (n == "verlet_bound_pending") *v = c->vl_bound_pending ? 1 : 0;  // a drift since the last poll / build: ls1hip_verlet_poll may be asked
 	else if (n == "last_force_kernel") *v = c->last_force_kernel;

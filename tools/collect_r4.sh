@@ -14,6 +14,8 @@ cp gpurun_out/prof_r4/bench_under_profiler.json $O/bench_under_profiler.json
 cp gpurun_out/prof_r4/kernel_stats_timed_window.txt $O/kernel_stats_timed_window.txt
 echo "profiles done"
 for wl in ethane mixed; do
+  # (PMC passes of the multi-site workloads: VALU / LDS busy, FP64 share, traffic of the pair-stream force pass)
+  bash tools/collect_profiles.sh r4_$wl --workload $wl > $O/collect_profiles_$wl.log 2>&1 && cp gpurun_out/prof_r4_$wl/pmc_summary.json $O/pmc_$wl.json
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$wl -- python3 bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline --no-live-pmc > $O/bench_${wl}_under_profiler.json 2> $O/stats_$wl.log
   f=$(ls $O/stats_$wl/*/*kernel_stats.csv | head -1); cp "$f" $O/kernel_stats_$wl.csv; rm -rf $O/stats_$wl
   echo "stats $wl done"

@@ -8,14 +8,22 @@
 //
 //   * the SEARCH runs once per list lifetime (cell grid, halo shell and lists with rc + skin; the device-side displacement
 //     bound of the drift passes decides about the rebuild — the machinery of the single-centre lists, ls1hip_update);
-//   * the list is not per molecule but per WAVE: a group of 128 consecutive owned molecules owns one contiguous block of
-//     molecule PAIRS (i local, j); a lane of the force pass takes one pair, so every lane has work whatever the neighbour counts
-//     of the individual molecules are (blocks are padded to a multiple of 64 only);
-//   * within a block the pairs are sorted by COMPONENT PAIR (c_i, c_j): a trip of 64 pairs sees one or two component pairs,
-//     each evaluated with wave-uniform component indices — site loops of uniform length, parameter tables through scalar loads;
-//   * no staging phases and no barriers: the group's own molecules sit in 13 KB of LDS per wave, partners are gathered through
-//     L2 (cell-sorted arrays), and a pair that crosses a periodic face refers to the SOURCE molecule plus a shift index instead
-//     of a halo copy — lists survive without any halo refresh (positions AND orientations of images follow their source).
+//   * the list is not per molecule but per WAVE: a group of 128 (one LJ-only component: 64) owned molecules owns one contiguous
+//     block of molecule PAIRS (i local, j); the lanes of the force pass work through the block 64 pairs at a time, so every lane has
+//     work whatever the neighbour counts of the individual molecules are (blocks are padded to a multiple of 64 only);
+//   * within a block the pairs are sorted by COMPONENT PAIR (c_i, c_j), then by local molecule; with several components the groups
+//     themselves are formed by component (k_msl_groups: a slot map inside windows of 1024 molecules, the state arrays keep their
+//     order), so that a group sees few component pairs with long runs;
+//   * round 4 — FILTER and QUEUE: a trip of 64 listed pairs only tests the cutoff (first 32 bytes of the partner's record) and
+//     appends the pairs inside to a per-wave queue in LDS; the pair BODIES run over 64 queue entries of ONE component pair —
+//     wave-uniform component indices (site loops of uniform length, parameter tables through scalar loads), no lanes idling for
+//     the pairs of the skin or for the other component pair of a trip;
+//   * no staging phases and no barriers: the group's own molecules sit in 9-15 KB of LDS per wave, partners are gathered through
+//     L2 as one 64-byte record per molecule, and a pair that crosses a periodic face refers to the SOURCE molecule plus a shift
+//     index instead of a halo copy — lists survive without any halo refresh (positions AND orientations of images follow their
+//     source);
+//   * single-component rigid sets: the epilogue integrates the group's own molecules (leapfrog_body.hpp) — between the steps of
+//     ls1hip_run forces and torques never reach memory.
 //
 // Forces are one-sided as everywhere in this library (each ordered pair evaluated for the molecule that receives the force):
 // the pair's force / torque on i is added to i's accumulator in the wave's LDS block (ds_add_f64 by the lanes of ONE wave: the
@@ -25,7 +33,8 @@
 //
 // Reference semantics: pair set and masks as kernels_force.hip (VectorizedCellProcessor.cpp:2734-2821, centre-of-mass cutoff,
 // strict <, r^2 != 0), bodies = mol_pair (molpair.hpp: potforce.h:282-503), macroscopic sums with weight 1/2 per ordered pair.
-// Precedent for list reuse in the reference: AutoPasContainer.cpp:281-346.
+// Precedent for list reuse in the reference: AutoPasContainer.cpp:281-346; for compacting the pairs inside the cutoff ahead of the
+// force body: the gather variant of vectorization/MaskGatherChooser.h:87-105 (hit indices compacted, bodies over full vectors).
 // pair arithmetic of THIS translation unit: FMA contraction on, reciprocals / square roots by the hardware estimate + two
 // Newton steps (see pairphys.hpp); results stay within 1e-13 of the IEEE bodies of the other kernels
 #pragma clang fp contract(fast)

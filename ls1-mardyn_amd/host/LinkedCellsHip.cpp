@@ -249,10 +249,15 @@ void LinkedCellsHip::uploadFromMirror() {
 										 sim->getLJCutoff())))
 		die("ls1hip_set_components", rc);
 	if ((rc = ls1hip_set_option(_ctx, "cells_in_cutoff", mirror().getHaloWidthNumCells()))) die("ls1hip_set_option", rc);
-	// neighbour lists with a skin (ls1hip_set_verlet): on by default with 8 % of the cutoff, LS1HIP_SKIN=<length> overrides,
-	// LS1HIP_SKIN=0 keeps the reference's search-every-step scheme.  The engine falls back by itself where lists do not apply
-	// (multi-site components, two cells per cutoff, regions beyond its staging capacity).
-	_skin = 0.08 * sim->getcutoffRadius();
+	// neighbour lists with a skin (ls1hip_set_verlet): on by default, LS1HIP_SKIN=<length> overrides, LS1HIP_SKIN=0 keeps the
+	// reference's search-every-step scheme.  Default: 8 % of the cutoff for the single-centre LJ lists (every listed pair costs a
+	// full pair evaluation), 15 % for multi-site sets (their list pass filters the listed pairs by the cutoff first, a pair of the
+	// skin costs a few instructions: profiles/r4_ms_skin_sweep.txt, r4_seam_b_speed.txt).  The engine falls back by itself where
+	// lists do not apply (two cells per cutoff, regions beyond its staging capacity).
+	bool single_centre = true;
+	for (const Component& comp : *(sim->getEnsemble()->getComponents())) single_centre = single_centre && comp.numSites() == 1 && comp.numLJcenters() == 1;
+	single_centre = single_centre && sim->getEnsemble()->getComponents()->size() == 1;
+	_skin = (single_centre ? 0.08 : 0.15) * sim->getcutoffRadius();
 	if (const char* e = getenv("LS1HIP_SKIN")) _skin = atof(e);
 	if (mirror().getHaloWidthNumCells() != 1) _skin = 0.;
 	// Multi-rank runs use the lists too (round 4: the default; LS1HIP_MULTIRANK_LISTS=0 searches every step).  Between two rebuilds a

@@ -310,8 +310,9 @@ int ls1hip_forces_list(ls1hip_ctx* ctx, int which, double dt, double* upot, doub
  * integrators/Leapfrog.cpp:66-150) in its epilogue: v += dt_half / m F with the kinetic sum of thermostat 0 (fetch it with
  * ls1hip_kinetic_sums), F is kept — the pass ls1hip_run takes on unfused steps (NVT, the last step), for drivers that call the
  * pieces themselves (the reference driver through LinkedCellsHip / LeapfrogHip: one pass over the molecules less per step).
- * Single-centre LJ list path only (read-only option "list_kick_available"); otherwise LS1HIP_EINVAL — use
- * ls1hip_forces_list + ls1hip_kick. */
+ * Single-centre LJ list path, and the pair-stream list pass of ONE rigid multi-site component (v, D kicked, sum m v^2 and sum I w^2
+ * of the step; same state as ls1hip_forces_list + ls1hip_kick bit for bit); read-only option "list_kick_available".  Otherwise
+ * (several components, per-molecule virial) LS1HIP_EINVAL — use ls1hip_forces_list + ls1hip_kick. */
 int ls1hip_forces_list_kick(ls1hip_ctx* ctx, double dt_half, double* upot, double* virial);
 int ls1hip_verlet_poll(ls1hip_ctx* ctx, int* need_rebuild);
 

@@ -89,6 +89,12 @@ bool can_fuse_ms(const ls1hip_ctx* c) {
 		   !c->opt_count_pairs && !c->thermostat_on && !c->has_remote;
 }
 
+// ... and the same sets may have the post-force kick + kinetic sums of a step folded into the list pass (thermostat or not)
+bool can_list_kick_ms(const ls1hip_ctx* c) {
+	return c->have_comp && !c->one_clj && c->h_ct.has_rot && c->h_ct.ncomp == 1 && c->opt_force_kernel != LS1HIP_FK_GENERIC && !c->opt_vi &&
+		   !c->opt_count_pairs && !c->has_remote;
+}
+
 extern "C" int ls1hip_set_option(ls1hip_ctx* c, const char* name, long v) {
 	if (!c || !name) return LS1HIP_EINVAL;
 	std::string n(name);
@@ -171,7 +177,7 @@ extern "C" int ls1hip_get_option(const ls1hip_ctx* c, const char* name, long* v)
 	} else if (n == "precision_in_use") *v = (c->opt_precision && c->vl_ready && c->vl_all_regular) ? c->opt_precision : 0;
 	else if (n == "can_fuse_integration") *v = can_fuse(c) ? 1 : 0;
 	else if (n == "can_fuse_rigid_lists") *v = (c->vl_on && can_fuse_ms(c)) ? 1 : 0;
-	else if (n == "list_kick_available") *v = (c->vl_ready && c->one_clj) ? 1 : 0;
+	else if (n == "list_kick_available") *v = (c->vl_ready && (c->one_clj || can_list_kick_ms(c))) ? 1 : 0;
 	else if (n == "verlet_bound_pending") *v = c->vl_bound_pending ? 1 : 0;  // a drift since the last poll / build: ls1hip_verlet_poll may be asked
 	else if (n == "last_force_kernel") *v = c->last_force_kernel;
 	else if (n == "build_variant") *v = (&ls1hip_variant_marker != nullptr) ? 1 : 0;  // 0 = the regular build (no timing-variant object inside)

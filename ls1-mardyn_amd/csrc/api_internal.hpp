@@ -133,6 +133,7 @@ static inline void free_cells(ls1hip_ctx* c) {
 // ---- helpers defined in one translation unit and used by another ---------------------------------------------------------------
 LS1_INTERNAL bool can_fuse(const ls1hip_ctx* c);
 LS1_INTERNAL bool can_fuse_ms(const ls1hip_ctx* c);
+LS1_INTERNAL bool can_list_kick_ms(const ls1hip_ctx* c);
 LS1_INTERNAL hipStream_t halo_stream(ls1hip_ctx* c);
 LS1_INTERNAL int sync_counters(ls1hip_ctx* c, hipStream_t s = nullptr);
 LS1_INTERNAL int d2h3(ls1hip_ctx* c, size_t n, const double* a, const double* b, const double* d, double* out, int stride, int o);

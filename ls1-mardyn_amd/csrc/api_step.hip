@@ -225,7 +225,9 @@ static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
 		// linear molecules (every LJ centre on the body z axis: ethane, the 2CLJ family): the axis form of the orientation
 		bool linear = lj_only;
 		for (int k = 0; k < c->h_ct.ncenters && linear; ++k) linear = c->h_ct.ljpos[k][0] == 0. && c->h_ct.ljpos[k][1] == 0.;
-		if (fuse) {  // the pass integrates its molecules itself: state in place, next step's records to the other record buffer
+		if (fuse || fp.post_kick) {
+			// fuse: the pass integrates its molecules itself — state in place, next step's records to the other record buffer, one
+			// drift speed per group; post_kick: it does the post-force kick and leaves {sum m v^2, sum I w^2, rot. DOF} per group
 			const MolSoA& ms = c->mol[c->cur];
 			P.Dx = ms.Dx; P.Dy = ms.Dy; P.Dz = ms.Dz;
 			P.msl_pk_out = c->d_msl_pk2;
@@ -238,6 +240,8 @@ static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
 			// the displacement bound of the lists, from the drift speeds the epilogue left per group (as track_unfused_drift)
 			launch_bound_update(c->d_cnt, P.msl_vmax, nblocks, fp.dt, 0.5 * c->vl_skin, c->vl_fresh, ++c->vl_seq, c->d_flag, c->stream, false);
 			std::swap(c->d_msl_pk, c->d_msl_pk2);
+		} else if (fp.post_kick) {
+			launch_kin_reduce(c->d_cnt, P.msl_vmax, nblocks, c->stream, c->thermostat_on ? c->thermostat_T : 0., c->log_row);
 		}
 		family = LS1HIP_FK_NEIGHBOUR_LIST;
 	} else if (fp.vl) {
@@ -276,8 +280,8 @@ static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
 	}
 	ReduceMode rm;
 	rm.overwrite = first_pass && !c->opt_count_pairs;
-	rm.kin_in_slot1 = (fuse && c->one_clj) || fp.post_kick;
-	rm.target_T = (fp.post_kick && c->thermostat_on) ? c->thermostat_T : 0.;
+	rm.kin_in_slot1 = (fuse || fp.post_kick) && c->one_clj;  // (multi-site list passes: their own partial buffers, see above)
+	rm.target_T = (fp.post_kick && c->thermostat_on && c->one_clj) ? c->thermostat_T : 0.;
 	rm.log = c->log_row;
 	if (fp.vl && fuse && c->one_clj) {
 		rm.vmax_in_slot2 = true;
@@ -861,7 +865,8 @@ extern "C" int ls1hip_forces_list(ls1hip_ctx* c, int which, double dt, double* u
 extern "C" int ls1hip_forces_list_kick(ls1hip_ctx* c, double dt_half, double* upot, double* virial) {
 	if (!c) return LS1HIP_EINVAL;
 	REQUIRE(c, dt_half > 0., "dt_half must be > 0");
-	REQUIRE(c, c->one_clj, "the post-force kick is folded into the single-centre LJ list pass only (ls1hip_forces_list + ls1hip_kick)");
+	REQUIRE(c, c->one_clj || can_list_kick_ms(c),
+			"the post-force kick is folded into the single-centre LJ list pass and into the pair-stream pass of ONE rigid component (otherwise: ls1hip_forces_list + ls1hip_kick)");
 	return forces_list_impl(c, 0, 2. * dt_half, true, upot, virial);
 }
 // post_kick (ls1hip_run, ls1hip_forces_list_kick): dt is the time step, the pass is NOT fused with the drift but does the post-force kick and
@@ -965,7 +970,7 @@ extern "C" int ls1hip_run(ls1hip_ctx* c, double dt, unsigned long nsteps, double
 	// neighbour-list loop (fused or not: NVT and unfused NVE steps advance the displacement bound in their kick + drift pass)
 	const bool verlet = can_verlet(c) && can_list(c);
 	// the single-centre list pass does the post-force kick (+ sum m v^2) itself; the multi-site one leaves it to the integrator passes
-	const bool list_kick = verlet && c->one_clj;
+	const bool list_kick = verlet && (c->one_clj || (can_list_ms(c) && can_list_kick_ms(c)));
 	bool advanced = false;  // the previous force pass already did kick + kick + drift
 	// step log: one row {U_pot, virial, sum m v^2, sum I w^2, N, rotDOF} per step, written by the reductions on the device
 	if (!c->d_steplog) {

@@ -598,6 +598,41 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
 		for (int o = 32; o > 0; o >>= 1) v2max = fmax(v2max, __shfl_down(v2max, o));
 		if (lane == 0) P.msl_vmax[grp] = v2max;
 		integrated = true;
+	} else if (P.fuse == 2) {
+		// POST-KICK (NVT loops, the driver's armed kick): upd_postF and the kinetic sums of the step for the group's molecules — the
+		// separate k_kick pass over v, D, q, F, M disappears.  F and M are stored (the pre-force kick of the next step needs them).
+		double mv2s = 0., Iw2s = 0., rdofs = 0.;
+		for (int k = lane; k < MSG; k += 64) {
+			const uint32_t p = msl_slot(P, p0 + (uint32_t)k);
+			if (p < n_real) {
+				const int c = sci[k];
+				LeapState st;
+				st.vx = P.vx[p]; st.vy = P.vy[p]; st.vz = P.vz[p];
+				st.q[0] = P.q0[p]; st.q[1] = P.q1[p]; st.q[2] = P.q2[p]; st.q[3] = P.q3[p];
+				st.D = {P.Dx[p], P.Dy[p], P.Dz[p]};
+				const V3 F = {acc[0][k], acc[1][k], acc[2][k]}, M = {acc[3][k], acc[4][k], acc[5][k]};
+				const V3 invI = {ct.invI[c][0], ct.invI[c][1], ct.invI[c][2]}, I = {ct.I[c][0], ct.I[c][1], ct.I[c][2]};
+				double mv2, Iw2;
+				leap_post<true>(0.5 * P.dt, ct.mass[c], invI, I, F, M, st, mv2, Iw2);
+				mv2s += mv2;
+				Iw2s += Iw2;
+				rdofs += (double)ct.rotdof[c];
+				P.vx[p] = st.vx; P.vy[p] = st.vy; P.vz[p] = st.vz;
+				P.Dx[p] = st.D.x; P.Dy[p] = st.D.y; P.Dz[p] = st.D.z;
+				P.Fx[p] = F.x; P.Fy[p] = F.y; P.Fz[p] = F.z;
+				P.Mx[p] = M.x; P.My[p] = M.y; P.Mz[p] = M.z;
+			}
+		}
+		mv2s = msl_wave_sum_d(mv2s);
+		Iw2s = msl_wave_sum_d(Iw2s);
+		rdofs = msl_wave_sum_d(rdofs);
+		if (lane == 0) {
+			double* const kp = P.msl_vmax + (size_t)grp * 4;  // (the buffer behind the macroscopic partials: [group][4] in this mode)
+			kp[0] = mv2s;
+			kp[1] = Iw2s;
+			kp[2] = rdofs;
+		}
+		integrated = true;
 	}
 	if (!integrated)
 	for (int k = lane; k < MSG; k += 64) {

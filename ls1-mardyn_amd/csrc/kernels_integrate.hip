@@ -148,28 +148,25 @@ __global__ void __launch_bounds__(ITPB) k_kick(IntegArgs a) {
 	const uint32_t p = blockIdx.x * ITPB + threadIdx.x;
 	double mv2 = 0., Iw2 = 0., rdof = 0.;
 	if (p < a.cnt->n_real) {
-		const double dt_halve = a.dt;
 		const int c = HAS_ROT ? a.mol.cid[p] : (a.ct->ncomp > 1 ? a.mol.cid[p] : 0);
-		const double m = a.ct->mass[c];
-		const double dtInv2m = dt_halve / m;
-		const double vx = a.mol.vx[p] + dtInv2m * a.frc.Fx[p];
-		const double vy = a.mol.vy[p] + dtInv2m * a.frc.Fy[p];
-		const double vz = a.mol.vz[p] + dtInv2m * a.frc.Fz[p];
-		a.mol.vx[p] = vx;
-		a.mol.vy[p] = vy;
-		a.mol.vz[p] = vz;
-		mv2 = m * (vx * vx + vy * vy + vz * vz);
-		rdof = (double)a.ct->rotdof[c];
+		// (the arithmetic: leapfrog_body.hpp, shared with the post-kick epilogue of the pair-stream list pass)
+		LeapState s;
+		s.vx = a.mol.vx[p]; s.vy = a.mol.vy[p]; s.vz = a.mol.vz[p];
+		const V3 F = {a.frc.Fx[p], a.frc.Fy[p], a.frc.Fz[p]};
+		V3 M = {0., 0., 0.}, invI = {0., 0., 0.}, I = {0., 0., 0.};
 		if (HAS_ROT) {
-			V3 D = {a.mol.Dx[p] + dt_halve * a.frc.Mx[p], a.mol.Dy[p] + dt_halve * a.frc.My[p],
-					a.mol.Dz[p] + dt_halve * a.frc.Mz[p]};
-			a.mol.Dx[p] = D.x;
-			a.mol.Dy[p] = D.y;
-			a.mol.Dz[p] = D.z;
-			V3 w = rotate_inv(rot_of(a.mol.q0[p], a.mol.q1[p], a.mol.q2[p], a.mol.q3[p]), D);
-			w = {w.x * a.ct->invI[c][0], w.y * a.ct->invI[c][1], w.z * a.ct->invI[c][2]};
-			Iw2 = a.ct->I[c][0] * w.x * w.x + a.ct->I[c][1] * w.y * w.y + a.ct->I[c][2] * w.z * w.z;
+			s.q[0] = a.mol.q0[p]; s.q[1] = a.mol.q1[p]; s.q[2] = a.mol.q2[p]; s.q[3] = a.mol.q3[p];
+			s.D = {a.mol.Dx[p], a.mol.Dy[p], a.mol.Dz[p]};
+			M = {a.frc.Mx[p], a.frc.My[p], a.frc.Mz[p]};
+			invI = {a.ct->invI[c][0], a.ct->invI[c][1], a.ct->invI[c][2]};
+			I = {a.ct->I[c][0], a.ct->I[c][1], a.ct->I[c][2]};
 		}
+		leap_post<HAS_ROT>(a.dt, a.ct->mass[c], invI, I, F, M, s, mv2, Iw2);
+		a.mol.vx[p] = s.vx; a.mol.vy[p] = s.vy; a.mol.vz[p] = s.vz;
+		if (HAS_ROT) {
+			a.mol.Dx[p] = s.D.x; a.mol.Dy[p] = s.D.y; a.mol.Dz[p] = s.D.z;
+		}
+		rdof = (double)a.ct->rotdof[c];
 	}
 	__shared__ double red[ITPB / 64][3];
 	mv2 = wave_sum_i(mv2);

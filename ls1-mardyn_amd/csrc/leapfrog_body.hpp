@@ -37,6 +37,24 @@ __device__ __forceinline__ void leap_q_diff(const double q[4], V3 w, double dq[4
 	dq[3] = .5 * (-q[2] * w.x + q[1] * w.y + q[0] * w.z);
 }
 
+// upd_postF alone (FullMolecule.cpp:366-389): v += dt/2m F, D += dt/2 M; returns m v^2 and I w^2 of the kicked state (q unchanged).
+// The body of k_kick and of the post-kick epilogue of the pair-stream list pass.
+template <bool HAS_ROT>
+__device__ __forceinline__ void leap_post(double dt_halve, double mass, V3 invI, V3 I, V3 F, V3 M, LeapState& s, double& mv2, double& Iw2) {
+#pragma clang fp contract(off)
+	const double dtInv2m = dt_halve / mass;
+	s.vx = s.vx + dtInv2m * F.x;
+	s.vy = s.vy + dtInv2m * F.y;
+	s.vz = s.vz + dtInv2m * F.z;
+	mv2 = mass * (s.vx * s.vx + s.vy * s.vy + s.vz * s.vz);
+	Iw2 = 0.;
+	if (HAS_ROT) {
+		s.D = {s.D.x + dt_halve * M.x, s.D.y + dt_halve * M.y, s.D.z + dt_halve * M.z};
+		const V3 w = leap_body_omega(s.q, s.D, invI);
+		Iw2 = I.x * w.x * w.x + I.y * w.y * w.y + I.z * w.z * w.z;
+	}
+}
+
 // s: state at the force evaluation (v and D half a step behind) -> position / orientation one step on, v and D half a step on.
 // Returns |v|^2 of the drift (the displacement bound of the neighbour lists).
 template <bool HAS_ROT>

@@ -325,18 +325,48 @@ def test_component_wise_thermostat_entry_points():
         assert rel_max(res[0][k], res[1][k]) < 1e-13, k
 
 
-def test_folded_post_force_kick_is_refused_for_multisite_sets():
-    """ls1hip_forces_list_kick serves the single-centre LJ list pass only: a multi-site set answers with an error (and says so in the
-    read-only option), the caller falls back to ls1hip_forces_list + ls1hip_kick — as LinkedCellsHip does."""
-    name = MULTISITE_FORCE_CASES[0]
-    case = MAN[name]
-    ps = inp.read_inp(input_path(case["input"]))
-    st = sorted_phase_space(ps)
-    e = _engine(ps, st, case["rc"], 0.07 * case["rc"], periodic=bool(case["periodic"]))
+def test_folded_post_force_kick_of_multisite_sets():
+    """ls1hip_forces_list_kick serves the single-centre LJ list pass and the pair-stream pass of ONE rigid component (round 4: the
+    epilogue does upd_postF and the kinetic sums — same state and sums as ls1hip_forces_list + ls1hip_kick, leapfrog_body.hpp); a set of
+    several components answers with an error (and says so in the read-only option), the caller falls back to the two calls — as
+    LinkedCellsHip does."""
+    comps, length, rc, ids, cid, r, v, q, D = _mixture_in_the_ethane_box()
+    # several components: refused
+    e = engine_mod.DeviceEngine(0)
+    e.set_components(comps, rc)
+    e.set_verlet(4.0)
+    e.set_domain(length)
+    e.upload(ids, cid, r, v, q, D)
     assert e.update() is True
     assert e.get_option("list_kick_available") == 0
     with pytest.raises(capi.Ls1HipError):
-        e.forces_list_kick(0.001)
+        e.forces_list_kick(0.25)
     e.forces_list(0, 0.0)  # the context is still usable
-    e.kick(0.001)
+    e.kick(0.25)
     e.close()
+    # one rigid component (ethane: LJ-only, groups of 64; the polar dumbbell: multipole body, groups of 128): folded = separate
+    for which in (0, 2):
+        one = inp.ComponentSet([comps.components[which]], np.zeros((0, 2)), 1e10)
+        res = []
+        for folded in (True, False):
+            e = engine_mod.DeviceEngine(0)
+            e.set_components(one, rc)
+            e.set_verlet(4.0)
+            e.set_domain(length)
+            e.upload(ids, np.zeros_like(cid), r, v, q, D)
+            assert e.update() is True
+            assert e.get_option("list_kick_available") == 1
+            if folded:
+                e.forces_list_kick(0.25)
+                sums = e.kinetic_sums()
+            else:
+                e.forces_list(0, 0.0)
+                sums = e.kick(0.25)
+            res.append((_sorted(e), sums))
+            e.close()
+        a, b = res
+        for k in ("v", "D", "F", "M"):
+            assert np.array_equal(a[0][k], b[0][k]), (which, k)
+        # (sum m v^2, sum I w^2, N, rotational DOF): the sums are reduced over groups instead of blocks of 256 — equal to rounding
+        assert a[1][2:] == b[1][2:] and a[1][2] == len(ids)
+        assert abs(a[1][0] - b[1][0]) <= 1e-12 * b[1][0] and abs(a[1][1] - b[1][1]) <= 1e-12 * b[1][1]

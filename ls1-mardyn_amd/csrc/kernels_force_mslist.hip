@@ -104,10 +104,12 @@ __device__ __forceinline__ double msl_dpp_d(double v) {
 template <int CTRL, int N>
 __device__ __forceinline__ void msl_seg_step(int key, double (&val)[N]) {
 	const bool same = msl_dpp_i<CTRL>(-1, key) == key;  // the lane CTRL's shift away (same row) feeds the same accumulator
+	double t[N];
 #pragma unroll
-	for (int c = 0; c < N; ++c) {
-		const double t = msl_dpp_d<CTRL>(val[c]);
-		val[c] += same ? t : 0.;
+	for (int c = 0; c < N; ++c) t[c] = msl_dpp_d<CTRL>(val[c]);  // (every lane takes part in the shifts)
+	if (same) {  // one exec mask for the N additions instead of two v_cndmask per value
+#pragma unroll
+		for (int c = 0; c < N; ++c) val[c] += t[c];
 	}
 }
 // after the call: val = sum over the lane's run up to and including the lane (inside its row of 16); returns whether the lane is

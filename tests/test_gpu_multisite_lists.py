@@ -166,14 +166,28 @@ def _mixture_in_the_ethane_box():
     return comps, ps.length, rc, st["ids"], cid, st["r"], st["v"], q, st["D"]
 
 
-@pytest.mark.parametrize("which", ["ethane", "mixture"])
+@pytest.mark.parametrize("which", ["ethane", "mixture", "linear_pair", "lj_rotors"])
 def test_multisite_list_loop_equals_per_step_kernels_over_many_rebuilds(which):
     """Several list lifetimes (hot start: a rebuild every few steps) — same trajectory as the search-every-step kernels;
-    "mixture": nine ordered component pairs sorted inside every wave's pair block, LJ and dipole sites."""
+    "mixture": nine ordered component pairs sorted inside every wave's pair block, LJ and dipole sites; "linear_pair": two linear
+    LJ-only components (the axis form of the orientation together with the slot map of several components); "lj_rotors": LJ-only
+    with a non-linear three-centre frame (the general LJ-only instantiation, two filter trips per iteration, slot map)."""
     comps, length, rc, ids, cid, r, v, q, D = _mixture_in_the_ethane_box()
     if which == "ethane":
         comps = inp.ComponentSet([comps.components[0]], np.zeros((0, 2)), 1e10)
         cid = np.zeros_like(cid)
+    elif which in ("linear_pair", "lj_rotors"):
+        eth = comps.components[0]
+        eps, sig = eth.lj[0][4], eth.lj[0][5]
+        short = inp.make_component(lj=[(0, 0, -1.2, 0.012, 1.1 * eps, 0.85 * sig, rc, 0), (0, 0, 1.2, 0.012, 1.1 * eps, 0.85 * sig, rc, 0)])
+        frame = inp.make_component(lj=[(0, 0.3, 0, 0.012, 0.9 * eps, 0.95 * sig, rc, 0), (1.2, -0.9, 0, 0.004, 0.3 * eps, 0.5 * sig, rc, 0),
+                                       (-1.2, -0.9, 0, 0.004, 0.3 * eps, 0.5 * sig, rc, 0)])
+        if which == "linear_pair":
+            comps = inp.ComponentSet([eth, short], np.array([[0.97, 1.03]]), 1e10)
+            cid = (np.arange(len(cid)) % 2).astype(np.int32)
+        else:
+            comps = inp.ComponentSet([eth, short, frame], np.array([[0.97, 1.03], [1.04, 0.99], [0.95, 1.01]]), 1e10)
+            cid = (np.arange(len(cid)) % 3).astype(np.int32)
     v = v * 3.0  # hot: the fastest molecules cross skin / 2 = 2 within two or three steps
     dt, steps, skin = 0.5, 40, 4.0
     res = {}

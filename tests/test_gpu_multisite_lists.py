@@ -280,6 +280,33 @@ def test_config3_ethane_10m_replicated_through_the_list_pass():
     e.close()
 
 
+def test_config4_mixed_10m_replicated_through_the_list_pass():
+    """configs[4] at full size through the round-4 list kernels (slot map of the five components, cutoff filter + queue): the box
+    of test_mixed_component_set_list_pass_against_oracle (2*12^3 molecules, checked against the pinned oracle here once more)
+    replicated 14^3 times = 9 483 264 molecules — every replica feels the small box's forces and torques, U_pot and virial are
+    k^3 times the small box's (tests/test_gpu_fullsize.py: periodic replication)."""
+    comps, length, ids, cid, r, q = _mixed_box(12)
+    rc = 35.0
+    ref = Oracle(comps.flat(), rc).forces(r, q, cid, length, True)
+    n0, k = len(ids), 14
+    n = n0 * k ** 3
+    e = engine_mod.DeviceEngine(0)
+    e.set_components(comps, rc)
+    e.set_verlet(2.5)
+    e.set_domain(length * k)
+    e.upload(np.arange(1, n + 1, dtype=np.uint64), tile(cid, k), replicate(length, r, k), np.zeros((n, 3)), tile(q, k), np.zeros((n, 3)))
+    e.update()
+    u, w = e.forces_list(0, 0.0, want_macro=True)
+    assert e.get_option("last_force_kernel") == capi.FK_NEIGHBOUR_LIST
+    stt = e.download_state()
+    o = np.argsort(stt["ids"], kind="stable")
+    f = e.download_forces()
+    big = dict(F=f["F"][o], M=f["M"][o], Vi=np.zeros((n, 3)), upot=u, virial=w)
+    small = dict(F=ref["F"], M=ref["M"], Vi=np.zeros((n0, 3)), upot=ref["upot"], virial=ref["virial"])
+    check_replicas(big, small, n0, k, np.random.default_rng(7))
+    e.close()
+
+
 def test_component_wise_thermostat_entry_points():
     """Several thermostats (Domain::severalThermostats; integrators/Leapfrog.cpp:84-104, thermostats/VelocityScalingThermostat.cpp:45-69):
     ls1hip_kinetic_sums_by_component == the sums of the downloaded state per component (sum m v^2, sum I w^2 through rotateinv and

@@ -252,6 +252,44 @@ def test_fused_rigid_body_list_pass_equals_the_separate_integrator_bitwise(which
             assert a[o][k] == b[o][k], k
 
 
+def test_piecewise_fused_rigid_body_loop_equals_ls1hip_run():
+    """The calls a driver makes itself — ls1hip_kick_drift, then per step ls1hip_update + ls1hip_forces_list(dt > 0) (the list pass
+    integrates the rigid bodies), the last step ls1hip_update + ls1hip_forces_list_kick — leave the state ls1hip_run leaves, bit for
+    bit (single-component rigid set; INTEGRATION.md, 'rigid multi-site sets under lists')."""
+    comps, length, rc, ids, cid, r, v, q, D = _mixture_in_the_ethane_box()
+    comps = inp.ComponentSet([comps.components[0]], np.zeros((0, 2)), 1e10)
+    cid = np.zeros_like(cid)
+    v = v * 3.0
+    dt, steps = 0.5, 19
+    res = []
+    for piecewise in (True, False):
+        e = engine_mod.DeviceEngine(0)
+        e.set_components(comps, rc)
+        e.set_verlet(4.0)
+        e.set_domain(length)
+        e.upload(ids, cid, r, v, q, D)
+        e.rebin(); e.halo(); e.forces(0)
+        if piecewise:
+            assert e.get_option("can_fuse_rigid_lists") == 1
+            e.kick_drift(dt)
+            for s in range(steps - 1):
+                e.update()
+                e.forces_list(0, dt)
+            e.update()
+            e.forces_list_kick(0.5 * dt)
+            kin = e.kinetic_sums()
+        else:
+            out = e.run(dt, steps)
+            kin = (out["summv2"], out["sumIw2"])
+        assert e.get_option("verlet_builds") >= 3
+        res.append((_sorted(e), kin))
+        e.close()
+    a, b = res
+    for k in ("r", "v", "q", "D", "F", "M"):
+        assert np.array_equal(a[0][k], b[0][k]), k
+    assert a[1][0] == b[1][0] and a[1][1] == b[1][1]
+
+
 def test_config3_ethane_10m_replicated_through_the_list_pass():
     """configs[3] at full size (the reference's ethane box replicated 10^3 = 9 826 000 molecules) through the list build and
     the list force pass: every replica reproduces the golden forces / torques of the real reference, U_pot and virial are

@@ -431,8 +431,8 @@ def live_pmc_compute(argv_tail, avg_launch_s, budget_s=300):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 50; mixed workload: 20)")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 10; mixed workload: 5)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 50; mixed workload: 40)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 10)")
     ap.add_argument("--n-per-dim", type=int, default=368,
                     help="bcc cells per dimension of the GLOBAL box (N = 2 n^3; 368 = the 10^8 box of the metric, 171 = configs[1])")
     ap.add_argument("--kernel", type=int, default=0, help="force kernel variant (LS1HIP_FK_*)")
@@ -476,11 +476,14 @@ def main():
     # The mixed set keeps the fixture's point multipoles (|mu| = 7.1 e a0 = 18 D, "modified to make the test more sensitive"): dipole
     # and charge sites sit 1-2 a0 off the molecules' centres and can meet inside the Lennard-Jones cores, so the liquid collapses
     # after ~6 time units (~100 steps at dt = 0.0612) WHATEVER the time step — the oracle and the reference binary show the same.
-    # Its timed window therefore lies early (5 + 20 steps + 10 profiling steps = 2.1 time units from the lattice start).
+    # Its timed window therefore lies early (10 + 40 steps + 10 profiling steps = 3.7 time units from the lattice start).
     if args.steps is None:
-        args.steps = 20 if args.workload == "mixed" else 50
+        # mixed: the lists of this box live ~20 steps (skin 5 a0) and the first build is at step 0 — 10 warm-up + 40 timed steps hold
+        # the rebuilds of steps ~20 and ~40: two per 40 steps, the steady-state density (`builds_in_timed_window`; a 20-step window
+        # held none or one: +- 8 % on `value`)
+        args.steps = 40 if args.workload == "mixed" else 50
     if args.warmup is None:
-        args.warmup = 5 if args.workload == "mixed" else 10
+        args.warmup = 10
     if args.workload == "mixed" and args.steps + args.warmup > 60:
         sys.exit("bench.py --workload mixed: keep warm-up + timed steps <= 60 (the set's point multipoles collapse after ~100 steps, see --help)")
     if args.melt < 0:
@@ -671,12 +674,12 @@ def main():
     e.timing_reset()
     e.timing_enable(2)  # the timed region carries the HIP-event pairs of the force launches only (roofline.avg_launch_ms)
     sync()
-    builds_before = int(e.get_option("verlet_builds")) if args.workload == "lj" else 0
+    builds_before = int(e.get_option("verlet_builds"))
     t0 = time.perf_counter()
     last = run(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
-    builds_in_window = (int(e.get_option("verlet_builds")) - builds_before) if args.workload == "lj" else None
+    builds_in_window = (int(e.get_option("verlet_builds")) - builds_before) if builds_before is not None else None
     e.timing_enable(0)
     force_ms, force_n = e.timing("force")
     # per-phase device times: a few extra steps with every phase timed, OUTSIDE the timed region
@@ -687,7 +690,7 @@ def main():
     sync()
     e.timing_enable(0)
     long_run = None
-    if args.workload == "lj" and world == 1 and not args.pmc_child and args.long_run > 0:
+    if args.workload in ("lj", "ethane") and world == 1 and not args.pmc_child and args.long_run > 0:  # (mixed: bounded window, see MIXED_DT)
         # secondary figure: a window long enough to average over the list lifetimes.  A rebuild step costs ~3 ordinary steps and comes
         # every ~11 steps, so a K-step window holds floor or ceil of K / 10.8 of them: +- 2 % on 50 steps, +- 5 % on the driver's 20
         b0 = int(e.get_option("verlet_builds"))

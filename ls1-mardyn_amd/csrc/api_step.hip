@@ -230,6 +230,8 @@ static int launch_forces(ls1hip_ctx* c, const ForcePass& fp) {
 			// drift speed per group; post_kick: it does the post-force kick and leaves {sum m v^2, sum I w^2, rot. DOF} per group
 			const MolSoA& ms = c->mol[c->cur];
 			P.Dx = ms.Dx; P.Dy = ms.Dy; P.Dz = ms.Dz;
+			P.ox = c->pos_x ? c->pos_x : ms.x; P.oy = c->pos_x ? c->pos_y : ms.y; P.oz = c->pos_x ? c->pos_z : ms.z;  // (= P.x y z, writable)
+			P.oq0 = ms.q0; P.oq1 = ms.q1; P.oq2 = ms.q2; P.oq3 = ms.q3;
 			P.msl_pk_out = c->d_msl_pk2;
 			P.msl_vmax = c->d_partials + (size_t)4 * msl_groups((uint32_t)c->n_real, P.msl_g);  // behind the macroscopic partials
 		}

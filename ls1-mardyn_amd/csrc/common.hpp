@@ -112,6 +112,7 @@ struct ForceParams {
 	// fused pair-stream pass of rigid bodies (fuse = 1): the epilogue integrates the group's molecules (leapfrog_body.hpp) — x y z,
 	// q, v (vx..), D in place, next step's records to msl_pk_out (the pass reads the other record buffer), max |v|^2 per group
 	double *Dx = nullptr, *Dy = nullptr, *Dz = nullptr;
+	double *ox = nullptr, *oy = nullptr, *oz = nullptr, *oq0 = nullptr, *oq1 = nullptr, *oq2 = nullptr, *oq3 = nullptr;  // x y z q, writable
 	double* msl_pk_out = nullptr;
 	double* msl_vmax = nullptr;
 	int count_pairs;

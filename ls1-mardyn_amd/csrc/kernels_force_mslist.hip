@@ -603,10 +603,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
 				const V3 F = {acc[0][k], acc[1][k], acc[2][k]}, M = {acc[3][k], acc[4][k], acc[5][k]};
 				const V3 invI = {ct.invI[c][0], ct.invI[c][1], ct.invI[c][2]};
 				v2max = fmax(v2max, leap_post_pre<true>(P.dt, ct.mass[c], invI, F, M, st));
-				const_cast<double*>(P.x)[p] = st.x; const_cast<double*>(P.y)[p] = st.y; const_cast<double*>(P.z)[p] = st.z;
+				P.ox[p] = st.x; P.oy[p] = st.y; P.oz[p] = st.z;
 				P.vx[p] = st.vx; P.vy[p] = st.vy; P.vz[p] = st.vz;
-				const_cast<double*>(P.q0)[p] = st.q[0]; const_cast<double*>(P.q1)[p] = st.q[1];
-				const_cast<double*>(P.q2)[p] = st.q[2]; const_cast<double*>(P.q3)[p] = st.q[3];
+				P.oq0[p] = st.q[0]; P.oq1[p] = st.q[1]; P.oq2[p] = st.q[2]; P.oq3[p] = st.q[3];
 				P.Dx[p] = st.D.x; P.Dy[p] = st.D.y; P.Dz[p] = st.D.z;
 				msl_write_record(P.msl_pk_out, p, st.x, st.y, st.z, st.q[0], st.q[1], st.q[2], st.q[3], true, c);
 			}
